@@ -1,0 +1,173 @@
+/*
+ * zotk.h -- C-ABI of libzotk.so, the MI355X (gfx950) k-mer counting and set-algebra core that
+ * sits under `zot kmerize | merge | dist | trim`.
+ *
+ * The reference (drtconway/zotmer, file:line relative to its root) has no FFI: its commands call
+ * pure-Python functions.  Each entry point below names the reference function it stands in for;
+ * INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only; no C++ or torch types cross this boundary;
+ *   - every function returns ZK_OK (0) or a negative ZK_E* code; zk_last_error(ctx) has the text;
+ *   - a zk_ctx is bound to one HIP device and one stream; calls on one ctx are serialised by the
+ *     caller; use one ctx per GPU (and per thread);
+ *   - pointers named d_* are DEVICE pointers (from zk_alloc, hipMalloc or a torch tensor's
+ *     data_ptr()); pointers without the prefix are host memory;
+ *   - work is queued on the ctx's stream; a function that returns a host scalar (n_out, acgt...)
+ *     has synchronised the stream before returning;
+ *   - k-mers are uint64, 2 bits per base, first base in the highest used bits (A0 C1 G2 T/U3),
+ *     exactly basics.kmer (zotmer/library/basics.py:48-59).  1 <= K <= 32.
+ *   - a "base stream" is the concatenation of the sequences of a batch, each followed by one
+ *     byte that is not a base (the host parser keeps the line's '\n'); any byte outside
+ *     AaCcGgTtUu ends the windows that touch it, as in basics.kmersList (basics.py:329-339).
+ *     Stream pointers must be 16-byte aligned.
+ *
+ * There is no CPU fallback: without a visible MI355X zk_create returns NULL.
+ */
+#ifndef ZOTK_H
+#define ZOTK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZK_OK 0
+#define ZK_EINVAL (-1)    /* bad argument */
+#define ZK_ENOMEM (-2)    /* device memory / workspace exhausted */
+#define ZK_EHIP (-3)      /* HIP runtime error */
+#define ZK_ENOSPC (-4)    /* an output array is too small (capacity argument) */
+#define ZK_EOVERFLOW (-5) /* a count does not fit its type (reference: array('I'), kmerize.py:373-374) */
+#define ZK_EINTERNAL (-6) /* device-side failure */
+#define ZK_ERANGE (-7)    /* codec64: value >= 2^60 has no code (reference: IndexError, codec64.py:33-40) */
+
+typedef struct zk_ctx zk_ctx;
+
+/* ---- context and buffers ------------------------------------------------------------------ */
+zk_ctx* zk_create(int device, uint64_t workspace_bytes);   /* NULL when no such GPU */
+void zk_destroy(zk_ctx* ctx);
+const char* zk_last_error(zk_ctx* ctx);
+int zk_set_stream(zk_ctx* ctx, void* hip_stream);          /* borrow a hipStream_t (NULL: own stream) */
+void* zk_get_stream(zk_ctx* ctx);
+int zk_sync(zk_ctx* ctx);
+int zk_reserve(zk_ctx* ctx, uint64_t workspace_bytes);     /* grow the internal workspace now */
+int zk_mem_info(zk_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
+int zk_alloc(zk_ctx* ctx, uint64_t bytes, void** d_ptr);
+int zk_free(zk_ctx* ctx, void* d_ptr);
+int zk_upload(zk_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
+int zk_download(zk_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
+int zk_copy(zk_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes);   /* device to device, async */
+
+/* ---- K1/K2: encode ------------------------------------------------------------------------- */
+
+/* reads given as bases[offs[r] .. offs[r+1]) -> base stream (d_stream holds offs[n_reads] + n_reads
+ * bytes; read r starts at offs[r] + r and is followed by '\n').  For callers that hold the
+ * classic (bases, offsets) layout instead of text lines. */
+int zk_pack_reads(zk_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_offs, uint64_t n_reads, uint8_t* d_stream);
+
+/* basics.kmersList(K, seq, both) over every sequence of the stream (library/basics.py:303-347,
+ * called from reads.next, library/reads.py:108-117): k-mers in stream order, x then rc(x) per
+ * window when both != 0.  acgt (may be NULL) = histogram of the low base of every emitted k-mer
+ * (commands/kmerize.py:492-493).  d_out holds cap values; *n_out = values produced. */
+int zk_encode(zk_ctx* ctx, const uint8_t* d_stream, uint64_t n_bytes, int K, int both,
+              uint64_t* d_out, uint64_t cap, uint64_t* n_out, uint64_t acgt[4]);
+
+/* basics.sub(seed, p, x) as a filter (library/basics.py:252-259; commands/kmerize.py:494-509):
+ * keeps x iff float(murmer(x, seed)) / float(2**61 - 1) < p, compared in doubles. */
+int zk_subsample(zk_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint64_t seed, double p,
+                 uint64_t* d_out, uint64_t cap, uint64_t* n_out);
+
+/* ---- K3/K4: sort and count ------------------------------------------------------------------ */
+
+/* misc.radix_sort(key_bits, xs) (library/misc.py:400-424): ascending, in place. */
+int zk_sort_keys(zk_ctx* ctx, uint64_t* d_keys, uint64_t n, int key_bits);
+/* the same carrying a 32-bit payload (stable) */
+int zk_sort_pairs(zk_ctx* ctx, uint64_t* d_keys, uint32_t* d_vals, uint64_t n, int key_bits);
+/* the run-length half of kmerize.merge (commands/kmerize.py:41-132): distinct values of a sorted
+ * array and their multiplicities.  d_uniq may equal d_sorted. */
+int zk_rle(zk_ctx* ctx, const uint64_t* d_sorted, uint64_t n, uint64_t* d_uniq, uint32_t* d_counts,
+           uint64_t cap, uint64_t* n_unique);
+/* KmerAccumulator2.flush on an empty table (commands/kmerize.py:412-424): sort (destroys d_keys)
+ * then count. */
+int zk_sort_count(zk_ctx* ctx, uint64_t* d_keys, uint64_t n, int key_bits,
+                  uint64_t* d_uniq, uint32_t* d_counts, uint64_t cap, uint64_t* n_unique);
+
+/* ---- the fused kmerize batch ------------------------------------------------------------------ */
+#define ZK_KMERIZE_CANONICAL 0   /* default: sort one strand, mirror after counting (same result) */
+#define ZK_KMERIZE_BOTH 1        /* sort both strands literally, as the reference does */
+#define ZK_KMERIZE_SUBSAMPLE 2   /* -D FRAC -S SEED (commands/kmerize.py:469-478,494-509) */
+
+typedef struct {
+    uint64_t n_windows;     /* valid windows seen */
+    uint64_t n_instances;   /* k-mers the reference would have emitted = 2 * n_windows (kmerize.py:523-525) */
+    uint64_t n_unique;      /* entries written to d_kmers / d_counts */
+    uint64_t n_canonical;   /* distinct canonical k-mers (0 in ZK_KMERIZE_BOTH mode) */
+    uint64_t acgt[4];       /* acgt[x & 3] over every instance, before any filtering (kmerize.py:492-493) */
+} zk_kmerize_stats;
+
+/* One in-memory `zot kmerize` (commands/kmerize.py:490-546 with KmerAccumulator2, :370-437) over
+ * the base stream: sorted distinct k-mers of BOTH strands and their counts. */
+int zk_kmerize(zk_ctx* ctx, const uint8_t* d_stream, uint64_t n_bytes, int K, int flags, double p, uint64_t seed,
+               uint64_t* d_kmers, uint32_t* d_counts, uint64_t cap, zk_kmerize_stats* stats);
+
+/* hist[c] += 1 per distinct k-mer (commands/kmerize.py:543-545; merge.py:88-92), as ascending
+ * (value, frequency) pairs in HOST arrays of cap_bins entries.  count_bits is 32 or 64. */
+int zk_hist(zk_ctx* ctx, const void* d_counts, int count_bits, uint64_t n,
+            uint64_t* vals, uint64_t* freq, uint64_t cap_bins, uint64_t* n_bins);
+
+/* uint32 counts -> uint64 counts (kmerize keeps array('I'), merge works on Python ints) */
+int zk_widen_counts(zk_ctx* ctx, const uint32_t* d_in, uint64_t* d_out, uint64_t n);
+
+/* ---- K5/K6: union with summed counts ---------------------------------------------------------- */
+
+/* merge.merge (commands/merge.py:26-86) and the merge half of kmerize.merge: two sorted-unique
+ * (k-mer, count) lists -> one; equal k-mers add.  count_bits (32 or 64) is the element type of all
+ * three count arrays.  acgt_w (may be NULL): acgt_w[x & 3] += count (merge.py:159). */
+int zk_union_sum(zk_ctx* ctx, const uint64_t* d_xk, const void* d_xc, uint64_t nx,
+                 const uint64_t* d_yk, const void* d_yc, uint64_t ny,
+                 uint64_t* d_ok, void* d_oc, int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);
+
+/* mergeNinto (commands/merge.py:127-163; twin commands/kmerize.py:269-304): k sorted-unique lists
+ * with 64-bit counts -> one.  d_keys / d_counts / ns are HOST arrays of k device pointers / sizes. */
+int zk_merge_n(zk_ctx* ctx, int k, const uint64_t* const* d_keys, const uint64_t* const* d_counts, const uint64_t* ns,
+               uint64_t* d_ok, uint64_t* d_oc, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);
+
+/* ---- K8/K9: dist ------------------------------------------------------------------------------- */
+
+/* Measure.prep, set mode (commands/dist.py:43-49): y = x >> shift, adjacent duplicates dropped. */
+int zk_project_dedupe(zk_ctx* ctx, const uint64_t* d_kmers, uint64_t n, int shift,
+                      uint64_t* d_out, uint64_t cap, uint64_t* n_out);
+/* dist.split (library/dist.py:241-265): abc = (|X & Y|, |X \ Y|, |Y \ X|) of two sorted unique arrays. */
+int zk_split(zk_ctx* ctx, const uint64_t* d_x, uint64_t nx, const uint64_t* d_y, uint64_t ny, uint64_t abc[3]);
+
+/* ---- K10: trim ---------------------------------------------------------------------------------- */
+
+/* trim.trim (commands/trim.py:54-62): keep (x, f) iff f >= lo and (hi == 0 or f <= hi). */
+int zk_trim(zk_ctx* ctx, const uint64_t* d_kmers, const void* d_counts, int count_bits, uint64_t n,
+            uint64_t lo, uint64_t hi, uint64_t* d_ok, void* d_oc, uint64_t cap, uint64_t* n_out);
+
+/* ---- synthetic input (bench / tests) ------------------------------------- */
+
+/* Reads first .. first+count-1 of the counter-based generator (zotmer_amd/synth.py) as a base
+ * stream of count*(L+1) bytes.  genome == 0: uniform bases.  Thresholds are fractions of 2^32. */
+int zk_synth_reads(zk_ctx* ctx, uint64_t seed, uint64_t first, uint64_t count, int L, uint64_t genome,
+                   uint32_t sub_thr, uint32_t n_thr, uint8_t* d_stream);
+
+/* sum of x and of murmer(x, 0) * count over a counted set, mod 2^64: order-free checksums used by
+ * the full-size parity tests.  d_counts may be NULL (every count 1). */
+int zk_checksum(zk_ctx* ctx, const uint64_t* d_kmers, const uint32_t* d_counts, uint64_t n, uint64_t sums[3]);
+
+/* the same three sums over every k-mer instance (x and rc(x) of each valid window) of a base
+ * stream, computed straight from the stream without sorting anything */
+int zk_stream_checksum(zk_ctx* ctx, const uint8_t* d_stream, uint64_t n_bytes, int K, uint64_t sums[3]);
+
+/* internal key-source selectors (shared with the kernels) */
+#define ZK_KEYS_FORWARD 0
+#define ZK_KEYS_BOTH 1
+#define ZK_KEYS_CANONICAL 2
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZOTK_H */

@@ -1,0 +1,349 @@
+"""
+GPU parity: the HIP path, called through the C-ABI (zotmer_amd/native.py -> libzotk.so), against
+  (a) the golden vectors captured from the reference (tests/golden), and
+  (b) the CPU oracle (oracle/zk_oracle.c) on the same seeded inputs,
+bit-exact throughout (integer / byte work: no tolerance anywhere).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import zkoracle as zo
+from tests import _golden as G
+from zotmer_amd import native, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = native.Context(0)
+    yield c
+    c.close()
+
+
+def stream_of(reads):
+    return ("".join(r + "\n" for r in reads)).encode()
+
+
+# ---- synthetic input ------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("kw", [dict(genome=0, n_thr=synth.frac32(0.01)),
+                                dict(genome=5000, sub_thr=synth.frac32(0.005), n_thr=synth.frac32(0.0005)),
+                                dict(genome=150)])
+def test_synth_device_matches_numpy(ctx, kw):
+    for first, count, L in ((0, 777, 150), (12345, 300, 37)):
+        if kw.get("genome") and kw["genome"] < L:
+            continue
+        want = synth.base_stream(synth.DEFAULT_SEED, first, count, L, **kw)
+        got = ctx.synth_reads(synth.DEFAULT_SEED, first, count, L, **kw).to_host()
+        assert np.array_equal(got, want)
+
+
+# ---- K1 encode --------------------------------------------------------------------------------------
+
+def test_encode_golden_kmersList(ctx):
+    P = G.load_json("primitives")
+    for c in P["kmersList"]:
+        if c["k"] > 32:
+            continue
+        d = ctx.upload_stream(c["seq"].encode() + b"\n")
+        out, _ = ctx.encode(d, c["k"], c["both"])
+        assert [int(x) for x in out.to_host()] == c["out"], (c["k"], c["seq"], c["both"])
+
+
+@pytest.mark.parametrize("K", [1, 5, 16, 25, 31, 32])
+def test_encode_many_reads_vs_oracle(ctx, K):
+    reads = synth.read_strings(7, 0, 3000, 97, genome=0, n_thr=synth.frac32(0.02))
+    reads += ["", "ACGT", "acgtnACGTUuuuacgtacgtagcatgcatgcatcgatcgatgcatgcatgcatgcatgcatgca", "N" * 40, "A" * 100]
+    want = np.concatenate([zo.kmers_list(K, r, True) for r in reads])
+    d = ctx.upload_stream(stream_of(reads))
+    out, acgt = ctx.encode(d, K, True)
+    got = out.to_host()
+    assert np.array_equal(got, want)
+    assert acgt == [int(np.sum((want & np.uint64(3)) == np.uint64(b))) for b in range(4)]
+    out1, _ = ctx.encode(d, K, False)
+    assert np.array_equal(out1.to_host(), want[0::2])
+
+
+def test_pack_reads(ctx):
+    reads = synth.read_strings(9, 0, 500, 61, genome=0) + ["", "ACGT", "T" * 200]
+    bases = np.frombuffer("".join(reads).encode(), dtype=np.uint8)
+    offs = np.zeros(len(reads) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    s = ctx.pack_reads(ctx.upload(bases), ctx.upload(offs))
+    assert s.to_host().tobytes() == stream_of(reads)
+
+
+# ---- K3 sort ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 100, 8191, 8192, 8193, 100003, 1 << 20])
+@pytest.mark.parametrize("bits", [2, 9, 50, 64])
+def test_sort_keys(ctx, n, bits):
+    rng = np.random.default_rng(n * 131 + bits)
+    x = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+    if bits < 64:
+        x &= np.uint64((1 << bits) - 1)
+    got = ctx.sort_keys(ctx.upload(x), bits).to_host()
+    assert np.array_equal(got, np.sort(x))
+
+
+def test_sort_keys_adversarial(ctx):
+    n = 300001
+    for x in (np.full(n, 0x23c48f123c48f, dtype=np.uint64),
+              np.arange(n, dtype=np.uint64), np.arange(n, dtype=np.uint64)[::-1].copy(),
+              np.repeat(np.arange(17, dtype=np.uint64) << np.uint64(40), n // 17)):
+        got = ctx.sort_keys(ctx.upload(x), 50).to_host()
+        assert np.array_equal(got, np.sort(x))
+
+
+def test_sort_keys_golden_radix_sort(ctx):
+    g = G.load_json("primitives")["radix_sort"]
+    xs = np.load(G.GOLD + "/radix_sort_in.npz")["xs"]
+    got = ctx.sort_keys(ctx.upload(xs), g["bits"]).to_host()
+    assert hashlib.sha256(got.astype("<u8").tobytes()).hexdigest() == g["sha256_out"]
+
+
+@pytest.mark.parametrize("n", [1, 5000, 8192 * 3 + 5, 500000])
+def test_sort_pairs_is_stable(ctx, n):
+    rng = np.random.default_rng(n)
+    k = rng.integers(0, 1 << 12, size=n, dtype=np.uint64) << np.uint64(20)      # many duplicates
+    v = np.arange(n, dtype=np.uint32)
+    dk, dv = ctx.sort_pairs(ctx.upload(k), ctx.upload(v), 50)
+    order = np.argsort(k, kind="stable")
+    assert np.array_equal(dk.to_host(), k[order])
+    assert np.array_equal(dv.to_host(), v[order])
+
+
+# ---- K4 run-length count ---------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("in_place", [False, True])
+def test_rle(ctx, in_place):
+    rng = np.random.default_rng(5)
+    vals = np.sort(rng.choice(np.arange(1, 10 ** 7, dtype=np.uint64), size=30000, replace=False))
+    reps = rng.integers(1, 6, size=len(vals))
+    reps[100] = 7000            # a run across several 2048-element tiles
+    reps[101] = 2048
+    reps[-1] = 5000             # ... and one that ends the array
+    x = np.repeat(vals, reps)
+    u, c = ctx.rle(ctx.upload(x), in_place=in_place)
+    assert np.array_equal(u.to_host(), vals)
+    assert np.array_equal(c.to_host(), reps.astype(np.uint32))
+    # one long run only, and the empty array
+    u, c = ctx.rle(ctx.upload(np.full(100000, 42, dtype=np.uint64)))
+    assert u.to_host().tolist() == [42] and c.to_host().tolist() == [100000]
+    u, c = ctx.rle(ctx.upload(np.empty(0, dtype=np.uint64)))
+    assert u.n == 0 and c.n == 0
+
+
+def test_sort_count_vs_oracle(ctx):
+    reads = synth.read_strings(11, 0, 4000, 150, genome=30000, sub_thr=synth.frac32(0.005), n_thr=synth.frac32(0.0005))
+    inst = np.concatenate([zo.kmers_list(25, r, True) for r in reads])
+    u, c = ctx.sort_count(ctx.upload(inst), 50)
+    zs, ss = zo.rle_merge([], [], zo.radix_sort(50, inst))
+    assert np.array_equal(u.to_host(), zs) and np.array_equal(c.to_host(), ss)
+
+
+# ---- the kmerize batch -----------------------------------------------------------------------------------------
+
+def _check_kmerize(ctx, K, reads, km, ct, meta, flags=native.KMERIZE_CANONICAL, **kw):
+    d = ctx.upload_stream(stream_of(reads))
+    k, c, st = ctx.kmerize(d, K, flags, **kw)
+    assert np.array_equal(k.to_host(), km)
+    assert np.array_equal(c.to_host().astype(np.uint64), ct)
+    tot = float(sum(st.acgt))
+    assert [v / tot for v in st.acgt] == meta["acgt"]                      # kmerize.py:554-555
+    assert {str(a): b for a, b in ctx.hist(c).items()} == meta["hist"]     # kmerize.py:543-545
+    return st
+
+
+@pytest.mark.parametrize("name", G.KMERIZE_SYNTH_CASES)
+@pytest.mark.parametrize("flags", [native.KMERIZE_CANONICAL, native.KMERIZE_BOTH])
+def test_kmerize_golden(ctx, name, flags):
+    info, km, ct, _, _ = G.load_case(name)
+    st = _check_kmerize(ctx, info["K"], G.synth_reads(info), km, ct, info["meta"], flags)
+    assert st.n_instances == info["sum_counts"] and st.n_unique == info["n"]
+
+
+def test_kmerize_golden_edge_inputs(ctx):
+    info, km, ct, _, _ = G.load_case("g9_edge_fastq")
+    fq = G.fastq_seqs(info["fastq"])
+    _check_kmerize(ctx, 25, fq, km, ct, info["meta"])
+    info2, km2, ct2, _, _ = G.load_case("g9_edge_fasta")
+    fa = G.fasta_seqs(info2["fasta"])
+    _check_kmerize(ctx, 25, fa, km2, ct2, info2["meta"])
+    info3, km3, ct3, _, _ = G.load_case("g9_two_files")
+    _check_kmerize(ctx, 25, fq + fa, km3, ct3, info3["meta"])
+
+
+def test_kmerize_golden_subsample(ctx):
+    info, km, ct, _, _ = G.load_case("g10_kmerize_D0.8_S3")
+    for flags in (native.KMERIZE_CANONICAL, native.KMERIZE_BOTH):
+        _check_kmerize(ctx, 25, G.synth_reads(info), km, ct, info["meta"], flags | native.KMERIZE_SUBSAMPLE,
+                       p=info["D"], seed=info["S"])
+
+
+def test_subsample_golden_sub(ctx):
+    P = G.load_json("primitives")
+    for s in (0, 3):
+        for p in (0.0, 0.05, 0.8, 1.0, 4.0, 7.99, 8.0, 9.0):
+            rows = [r for r in P["sub"] if r[0] == s and r[1] == p]
+            xs = np.array([r[2] for r in rows], dtype=np.uint64)
+            got = ctx.subsample(ctx.upload(xs), s, p).to_host()
+            assert got.tolist() == [r[2] for r in rows if r[3]]
+
+
+def test_kmerize_config1_digest(ctx):
+    g = G.load_json("config1_digest")
+    d = ctx.upload_stream(synth.base_stream(**g["synth"]))
+    # the device generator gives the same stream
+    assert np.array_equal(ctx.synth_reads(**{k: v for k, v in g["synth"].items()}).to_host(), d.to_host())
+    k, c, st = ctx.kmerize(d, g["K"])
+    kh, ch = k.to_host(), c.to_host().astype(np.uint64)
+    assert len(kh) == g["n"] and int(ch.sum()) == g["sum_counts"] == st.n_instances
+    assert hashlib.sha256(kh.astype("<u8").tobytes()).hexdigest() == g["sha256_kmers"]
+    assert hashlib.sha256(ch.astype("<u8").tobytes()).hexdigest() == g["sha256_counts"]
+    assert {str(a): b for a, b in ctx.hist(c).items()} == g["meta"]["hist"]
+    tot = float(sum(st.acgt))
+    assert [v / tot for v in st.acgt] == g["meta"]["acgt"]
+
+
+def test_kmerize_empty_and_tiny(ctx):
+    for reads in ([], [""], ["ACGT"], ["N" * 100], ["A" * 25], ["ACGTACGTACGTACGTACGTACGTAC"]):
+        want = zo.kmerize(25, reads)
+        d = ctx.upload_stream(stream_of(reads)) if reads else ctx.empty(0, np.uint8)
+        for flags in (native.KMERIZE_CANONICAL, native.KMERIZE_BOTH):
+            k, c, st = ctx.kmerize(d, 25, flags)
+            assert np.array_equal(k.to_host(), want["kmers"]) and np.array_equal(c.to_host(), want["counts"])
+            assert list(st.acgt) == want["acgt"]
+
+
+@pytest.mark.parametrize("K", [4, 24, 32])
+def test_kmerize_even_K_palindromes_vs_oracle(ctx, K):
+    # even K: x == rc(x) exists; the mirrored path must count such a window twice, like two emissions
+    reads = synth.read_strings(3, 0, 2500, 80, genome=0, n_thr=synth.frac32(0.01)) + ["ACGT" * 20, "AATT" * 16, "GC" * 40]
+    want = zo.kmerize(K, reads)
+    d = ctx.upload_stream(stream_of(reads))
+    for flags in (native.KMERIZE_CANONICAL, native.KMERIZE_BOTH):
+        k, c, st = ctx.kmerize(d, K, flags)
+        assert np.array_equal(k.to_host(), want["kmers"]) and np.array_equal(c.to_host(), want["counts"])
+
+
+def test_kmerize_large_properties(ctx):
+    """2 M reads x 150 bp: too big for the fixtures; checked through order-free checksums taken straight
+    from the stream, sortedness, strand symmetry, and agreement of the two sort strategies."""
+    R, L, K = 2_000_000, 150, 25
+    d = ctx.synth_reads(synth.DEFAULT_SEED, 0, R, L, genome=4_000_000, sub_thr=synth.frac32(0.005), n_thr=synth.frac32(0.0005))
+    want = ctx.stream_checksum(d, K)
+    k, c, st = ctx.kmerize(d, K, native.KMERIZE_CANONICAL, cap=3 * R * (L - K + 1) // 2)
+    assert ctx.checksum(k, c) == want and st.n_instances == want[0]
+    kh, ch = k.to_host(), c.to_host()
+    assert np.all(kh[1:] > kh[:-1])
+    assert ch.sum(dtype=np.uint64) == want[0]
+    # strand symmetry: count(x) == count(rc x)
+    sub = np.arange(0, len(kh), 997)
+    rc = np.array([zo.rc(K, int(x)) for x in kh[sub]], dtype=np.uint64)
+    j = np.searchsorted(kh, rc)
+    assert np.array_equal(kh[j], rc) and np.array_equal(ch[j], ch[sub])
+    k2, c2, st2 = ctx.kmerize(d, K, native.KMERIZE_BOTH, cap=len(kh) + 16)
+    assert np.array_equal(k2.to_host(), kh) and np.array_equal(c2.to_host(), ch)
+    assert list(st2.acgt) == list(st.acgt)
+    # the same reads through the oracle on a 20 000-read prefix
+    pre = ctx.synth_reads(synth.DEFAULT_SEED, 0, 20000, L, genome=4_000_000, sub_thr=synth.frac32(0.005), n_thr=synth.frac32(0.0005))
+    reads = pre.to_host().tobytes().decode().split("\n")[:-1]
+    w = zo.kmerize(K, reads)
+    k3, c3, _ = ctx.kmerize(pre, K)
+    assert np.array_equal(k3.to_host(), w["kmers"]) and np.array_equal(c3.to_host(), w["counts"])
+
+
+# ---- K5/K6 union-sum ----------------------------------------------------------------------------------------------
+
+def test_merge_golden(ctx):
+    parts = [G.load_case("g4_part%d" % i) for i in range(5)]
+    dev = [(ctx.upload(p[1]), ctx.upload(p[2])) for p in parts]
+    for n in (2, 3, 4, 5):
+        info, km, ct, _, _ = G.load_case("g4_merge%d" % n)
+        k, c, acgt = ctx.merge_n(dev[:n])
+        assert np.array_equal(k.to_host(), km) and np.array_equal(c.to_host(), ct)
+        assert {str(a): b for a, b in ctx.hist(c).items()} == info["meta"]["hist"]
+        if n > 2:
+            tot = float(sum(acgt))
+            assert [v / tot for v in acgt] == info["meta"]["acgt"]     # merge.py:159,245-246
+    # 2-way, both count widths
+    _, km, ct, _, _ = G.load_case("g4_merge2")
+    k, c = ctx.union_sum(dev[0][0], dev[0][1], dev[1][0], dev[1][1])
+    assert np.array_equal(k.to_host(), km) and np.array_equal(c.to_host(), ct)
+    a32 = (dev[0][0], ctx.upload(parts[0][2].astype(np.uint32)))
+    b32 = (dev[1][0], ctx.upload(parts[1][2].astype(np.uint32)))
+    k, c = ctx.union_sum(a32[0], a32[1], b32[0], b32[1])
+    assert np.array_equal(k.to_host(), km) and np.array_equal(c.to_host().astype(np.uint64), ct)
+
+
+@pytest.mark.parametrize("nx,ny", [(0, 0), (0, 10), (10, 0), (1, 1), (2047, 2049), (100000, 3), (300000, 250000)])
+def test_union_sum_random_vs_oracle(ctx, nx, ny):
+    rng = np.random.default_rng(nx * 7 + ny)
+    pool = np.sort(rng.choice(np.arange(1 << 22, dtype=np.uint64), size=max(nx + ny, 1), replace=False))
+    x = np.sort(rng.choice(pool, size=nx, replace=False)) if nx else np.empty(0, np.uint64)
+    y = np.sort(rng.choice(pool, size=ny, replace=False)) if ny else np.empty(0, np.uint64)
+    xc = rng.integers(1, 1000, size=nx, dtype=np.uint64)
+    yc = rng.integers(1, 1000, size=ny, dtype=np.uint64)
+    zs, zc = zo.union_sum(x, xc, y, yc)
+    k, c, acgt = ctx.union_sum(ctx.upload(x), ctx.upload(xc), ctx.upload(y), ctx.upload(yc), want_acgt=True)
+    assert np.array_equal(k.to_host(), zs) and np.array_equal(c.to_host(), zc)
+    assert acgt == [int(zc[(zs & np.uint64(3)) == np.uint64(b)].sum()) for b in range(4)]
+    # identical inputs: everything pairs up
+    k, c = ctx.union_sum(ctx.upload(x), ctx.upload(xc), ctx.upload(x), ctx.upload(xc))
+    assert np.array_equal(k.to_host(), x) and np.array_equal(c.to_host(), 2 * xc)
+
+
+def test_merge_n_random_vs_oracle(ctx):
+    rng = np.random.default_rng(99)
+    for k in (1, 2, 3, 7, 8, 13):
+        sets = []
+        for s in range(k):
+            n = int(rng.integers(0, 40000))
+            x = np.sort(rng.choice(np.arange(1 << 18, dtype=np.uint64) << np.uint64(30), size=n, replace=False))
+            sets.append((x, rng.integers(1, 50, size=n, dtype=np.uint64)))
+        zs, zc, acgt = zo.merge_n(25, sets)
+        gk, gc, gacgt = ctx.merge_n([(ctx.upload(a), ctx.upload(b)) for a, b in sets])
+        assert np.array_equal(gk.to_host(), zs) and np.array_equal(gc.to_host(), zc) and gacgt == acgt
+
+
+# ---- K8/K9 dist --------------------------------------------------------------------------------------------------
+
+def test_dist_golden(ctx):
+    g = G.load_json("g5_dist")
+    p0 = ctx.upload(G.load_case("g4_part0")[1])
+    p1 = ctx.upload(G.load_case("g4_part1")[1])
+    for k, t in g["split_part0_part1"].items():
+        sh = 2 * (25 - int(k))
+        x, y = ctx.project_dedupe(p0, sh), ctx.project_dedupe(p1, sh)
+        assert (x.n, y.n) == (t["nx"], t["ny"])
+        assert list(ctx.split(x, y)) == t["abc"]
+
+
+@pytest.mark.parametrize("nx,ny", [(0, 0), (0, 5), (5, 0), (1, 1), (4096, 4096), (100001, 77), (400000, 380000)])
+def test_split_random_vs_oracle(ctx, nx, ny):
+    rng = np.random.default_rng(nx + 3 * ny)
+    pool = np.arange(1, 1 << 21, dtype=np.uint64) * np.uint64(0x1f3)
+    x = np.sort(rng.choice(pool, size=nx, replace=False)) if nx else np.empty(0, np.uint64)
+    y = np.sort(rng.choice(pool, size=ny, replace=False)) if ny else np.empty(0, np.uint64)
+    assert ctx.split(ctx.upload(x), ctx.upload(y)) == zo.split(x, y)
+    assert ctx.split(ctx.upload(x), ctx.upload(x)) == (nx, 0, 0)
+    for sh in (0, 4, 20):
+        assert np.array_equal(ctx.project_dedupe(ctx.upload(x), sh).to_host(), zo.project_dedupe(x, sh))
+
+
+# ---- K10 trim -------------------------------------------------------------------------------------------------------
+
+def test_trim_golden(ctx):
+    _, km, ct, _, _ = G.load_case("g3_kmerize_genome")
+    dk = ctx.upload(km)
+    for name in ("g6_trim_c3", "g6_trim_c2_C9"):
+        info, tk, tc, _, _ = G.load_case(name)
+        for cdt in (np.uint64, np.uint32):
+            k, c = ctx.trim(dk, ctx.upload(ct.astype(cdt)), info["c"], info["C"])
+            assert np.array_equal(k.to_host(), tk) and np.array_equal(c.to_host().astype(np.uint64), tc)
+    k, c = ctx.trim(dk, ctx.upload(ct), 10 ** 9)
+    assert k.n == 0

@@ -1,0 +1,266 @@
+// capi.hip -- the extern "C" surface of libzotk.so (include/zotk.h) over the launchers, plus the
+// small kernels that belong to no other file: read packing, synthetic reads, checksums.
+#include "internal.hpp"
+#include "encode_tile.hpp"
+
+namespace zk {
+int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, double p, uint64_t seed, u64* out_k, u32* out_c,
+            uint64_t cap, zk_kmerize_stats* st);
+int merge_many(zk_ctx* c, int k, const u64* const* keys, const u64* const* cnts, const uint64_t* ns, u64* out_k, u64* out_c,
+               uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);
+int widen_counts(zk_ctx* c, const u32* in, u64* out, uint64_t n);
+
+// ---- (bases, offsets) -> base stream ----------------------------------------------------------
+__global__ void pack_reads_kernel(const u8* __restrict__ bases, const u64* __restrict__ offs, u64 n_reads, u8* __restrict__ out) {
+    // one wave per read
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const u64 nw = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 r = wave; r < n_reads; r += nw) {
+        const u64 b = offs[r], e = offs[r + 1];
+        u8* o = out + b + r;
+        for (u64 i = lane; i < e - b; i += 64) o[i] = bases[b + i];
+        if (lane == 0) o[e - b] = '\n';
+    }
+}
+
+// ---- synthetic reads (zotmer_amd/synth.py is the specification) --------------------------------
+__device__ __forceinline__ u64 mix64(u64 z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+struct SynthArgs { u64 seed, first, count; int L; u64 genome; u32 sub_thr, n_thr; };
+__global__ void synth_kernel(SynthArgs a, u8* __restrict__ out) {
+    const u64 s1 = mix64(a.seed + 1), s2 = mix64(a.seed + 2), s3 = mix64(a.seed + 3), s4 = mix64(a.seed + 4),
+              s5 = mix64(a.seed + 5), s6 = mix64(a.seed + 6);
+    const u64 total = a.count * (u64)(a.L + 1);
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (u64)gridDim.x * blockDim.x) {
+        const u64 k = t / (u64)(a.L + 1);
+        const int j = (int)(t - k * (u64)(a.L + 1));
+        if (j == a.L) { out[t] = '\n'; continue; }
+        const u64 i = a.first + k;
+        const u64 idx = i * (u64)a.L + (u64)j;
+        u64 b;
+        const u64 e = mix64(s4 + idx);
+        if (a.genome) {
+            const u64 start = mix64(s2 + i) % (a.genome - (u64)a.L + 1);
+            const u64 strand = mix64(s3 + i) & 1;
+            const u64 gpos = strand ? start + (u64)(a.L - 1 - j) : start + (u64)j;
+            b = mix64(s1 + gpos) & 3;
+            if (strand) b = 3 - b;
+            if (a.sub_thr && (u32)(e & 0xFFFFFFFFull) < a.sub_thr) b = (b + 1 + mix64(s5 + idx) % 3) & 3;
+        } else {
+            b = mix64(s6 + idx) & 3;
+        }
+        u8 ch = "ACGT"[b];
+        if (a.n_thr && (u32)(e >> 32) < a.n_thr) ch = 'N';
+        out[t] = ch;
+    }
+}
+
+// ---- checksums ---------------------------------------------------------------------------------
+__global__ void checksum_kernel(const u64* __restrict__ k, const u32* __restrict__ c, u64 n, u64* sums) {
+    u64 s0 = 0, s1 = 0, s2 = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 w = c ? (u64)c[i] : 1ull;
+        s0 += w; s1 += k[i] * w; s2 += murmer(k[i], 0) * w;
+    }
+    s0 = wave_sum_u64(s0); s1 = wave_sum_u64(s1); s2 = wave_sum_u64(s2);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1); atomicAdd(&sums[2], s2); }
+}
+
+constexpr int CS_BLOCK = 256, CS_ITEMS = 8, CS_TILE = CS_BLOCK * CS_ITEMS;
+__global__ __launch_bounds__(CS_BLOCK) void stream_checksum_kernel(const u8* __restrict__ stream, u64 n_bytes, int K, u32 tiles, u64* sums) {
+    __shared__ TileImage<CS_TILE> img;
+    u64 s0 = 0, s1 = 0, s2 = 0;
+    for (u32 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        stage_tile<CS_BLOCK, CS_TILE>(stream, n_bytes, (u64)tile * CS_TILE, img);
+#pragma unroll
+        for (int i = 0; i < CS_ITEMS; i++) {
+            u64 x;
+            if (window_at(img, (int)threadIdx.x + i * CS_BLOCK, K, x)) {
+                const u64 xb = revcomp(K, x);
+                s0 += 2; s1 += x + xb; s2 += murmer(x, 0) + murmer(xb, 0);
+            }
+        }
+        __syncthreads();
+    }
+    s0 = wave_sum_u64(s0); s1 = wave_sum_u64(s1); s2 = wave_sum_u64(s2);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1); atomicAdd(&sums[2], s2); }
+}
+
+static u32 grid_for(zk_ctx* c, u64 n, u64 per_block) {
+    u64 g = div_up(n, per_block), mx = (u64)c->num_cus * 16;
+    return (u32)(g < mx ? (g ? g : 1) : mx);
+}
+}  // namespace zk
+
+using namespace zk;
+
+#define ZK_ARGS(c, cond) do { if (!(c)) return ZK_EINVAL; if (!(cond)) return zk::fail((c), ZK_EINVAL, "bad argument: %s", #cond); } while (0)
+
+extern "C" {
+
+int zk_pack_reads(zk_ctx* c, const uint8_t* d_bases, const uint64_t* d_offs, uint64_t n_reads, uint8_t* d_stream) {
+    ZK_ARGS(c, d_offs && d_stream);
+    if (n_reads == 0) return ZK_OK;
+    hipLaunchKernelGGL(pack_reads_kernel, dim3(grid_for(c, n_reads, 4)), dim3(256), 0, c->stream, d_bases, (const u64*)d_offs, (u64)n_reads, d_stream);
+    ZK_HIP(c, hipGetLastError());
+    return ZK_OK;
+}
+
+int zk_encode(zk_ctx* c, const uint8_t* d_stream, uint64_t n_bytes, int K, int both, uint64_t* d_out, uint64_t cap,
+              uint64_t* n_out, uint64_t acgt[4]) {
+    ZK_ARGS(c, n_out && K >= 1 && K <= 32);
+    arena_reset(c);
+    return encode_list(c, d_stream, n_bytes, K, both ? 1 : 0, (u64*)d_out, cap, n_out, acgt);
+}
+
+int zk_subsample(zk_ctx* c, const uint64_t* d_kmers, uint64_t n, uint64_t seed, double p, uint64_t* d_out, uint64_t cap,
+                 uint64_t* n_out) {
+    ZK_ARGS(c, n_out);
+    arena_reset(c);
+    return subsample(c, (const u64*)d_kmers, n, seed, p, (u64*)d_out, cap, n_out);
+}
+
+int zk_sort_keys(zk_ctx* c, uint64_t* d_keys, uint64_t n, int key_bits) {
+    ZK_ARGS(c, key_bits >= 1 && key_bits <= 64);
+    if (n == 0) return ZK_OK;
+    arena_reset(c);
+    ZK_TRY(arena_require(c, 8 * n + (1 << 20), 8 * n + (1 << 20)));
+    u64 *alt, *res;
+    ZK_TRY(arena_alloc(c, 8 * n, (void**)&alt));
+    ZK_TRY(sort_keys(c, (u64*)d_keys, alt, n, key_bits, &res));
+    if (res != (u64*)d_keys) ZK_HIP(c, hipMemcpyAsync(d_keys, res, 8 * n, hipMemcpyDeviceToDevice, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    return check_device_error(c);
+}
+
+int zk_sort_pairs(zk_ctx* c, uint64_t* d_keys, uint32_t* d_vals, uint64_t n, int key_bits) {
+    ZK_ARGS(c, key_bits >= 1 && key_bits <= 64);
+    if (n == 0) return ZK_OK;
+    arena_reset(c);
+    ZK_TRY(arena_require(c, 12 * n + (1 << 20), 12 * n + (1 << 20)));
+    u64 *alt, *rk; u32 *valt, *rv;
+    ZK_TRY(arena_alloc(c, 8 * n, (void**)&alt));
+    ZK_TRY(arena_alloc(c, 4 * n, (void**)&valt));
+    ZK_TRY(sort_pairs(c, (u64*)d_keys, alt, d_vals, valt, n, key_bits, &rk, &rv));
+    if (rk != (u64*)d_keys) {
+        ZK_HIP(c, hipMemcpyAsync(d_keys, rk, 8 * n, hipMemcpyDeviceToDevice, c->stream));
+        ZK_HIP(c, hipMemcpyAsync(d_vals, rv, 4 * n, hipMemcpyDeviceToDevice, c->stream));
+    }
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    return check_device_error(c);
+}
+
+int zk_rle(zk_ctx* c, const uint64_t* d_sorted, uint64_t n, uint64_t* d_uniq, uint32_t* d_counts, uint64_t cap, uint64_t* n_unique) {
+    ZK_ARGS(c, n_unique);
+    arena_reset(c);
+    return rle(c, (const u64*)d_sorted, n, (u64*)d_uniq, d_counts, cap, n_unique);
+}
+
+int zk_sort_count(zk_ctx* c, uint64_t* d_keys, uint64_t n, int key_bits, uint64_t* d_uniq, uint32_t* d_counts, uint64_t cap,
+                  uint64_t* n_unique) {
+    ZK_ARGS(c, n_unique && key_bits >= 1 && key_bits <= 64);
+    *n_unique = 0;
+    if (n == 0) return ZK_OK;
+    arena_reset(c);
+    ZK_TRY(arena_require(c, 8 * n + n / 64 + (1 << 20), 8 * n + n / 64 + (1 << 20)));
+    u64 *alt, *res;
+    ZK_TRY(arena_alloc(c, 8 * n, (void**)&alt));
+    ZK_TRY(sort_keys(c, (u64*)d_keys, alt, n, key_bits, &res));
+    return rle(c, res, n, (u64*)d_uniq, d_counts, cap, n_unique);
+}
+
+int zk_kmerize(zk_ctx* c, const uint8_t* d_stream, uint64_t n_bytes, int K, int flags, double p, uint64_t seed,
+               uint64_t* d_kmers, uint32_t* d_counts, uint64_t cap, zk_kmerize_stats* stats) {
+    ZK_ARGS(c, stats);
+    return kmerize(c, d_stream, n_bytes, K, flags, p, seed, (u64*)d_kmers, d_counts, cap, stats);
+}
+
+int zk_hist(zk_ctx* c, const void* d_counts, int count_bits, uint64_t n, uint64_t* vals, uint64_t* freq, uint64_t cap_bins,
+            uint64_t* n_bins) {
+    ZK_ARGS(c, n_bins && (count_bits == 32 || count_bits == 64));
+    arena_reset(c);
+    return count_hist(c, d_counts, count_bits, n, vals, freq, cap_bins, n_bins);
+}
+
+int zk_widen_counts(zk_ctx* c, const uint32_t* d_in, uint64_t* d_out, uint64_t n) {
+    ZK_ARGS(c, true);
+    return widen_counts(c, d_in, (u64*)d_out, n);
+}
+
+int zk_union_sum(zk_ctx* c, const uint64_t* d_xk, const void* d_xc, uint64_t nx, const uint64_t* d_yk, const void* d_yc,
+                 uint64_t ny, uint64_t* d_ok, void* d_oc, int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]) {
+    ZK_ARGS(c, n_out && (count_bits == 32 || count_bits == 64));
+    arena_reset(c);
+    return union_sum(c, (const u64*)d_xk, d_xc, nx, (const u64*)d_yk, d_yc, ny, (u64*)d_ok, d_oc, count_bits, cap, n_out, acgt_w);
+}
+
+int zk_merge_n(zk_ctx* c, int k, const uint64_t* const* d_keys, const uint64_t* const* d_counts, const uint64_t* ns,
+               uint64_t* d_ok, uint64_t* d_oc, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]) {
+    ZK_ARGS(c, n_out && k >= 0);
+    return merge_many(c, k, (const u64* const*)d_keys, (const u64* const*)d_counts, ns, (u64*)d_ok, (u64*)d_oc, cap, n_out, acgt_w);
+}
+
+int zk_project_dedupe(zk_ctx* c, const uint64_t* d_kmers, uint64_t n, int shift, uint64_t* d_out, uint64_t cap, uint64_t* n_out) {
+    ZK_ARGS(c, n_out && shift >= 0 && shift < 64);
+    arena_reset(c);
+    return project_dedupe(c, (const u64*)d_kmers, n, shift, (u64*)d_out, cap, n_out);
+}
+
+int zk_split(zk_ctx* c, const uint64_t* d_x, uint64_t nx, const uint64_t* d_y, uint64_t ny, uint64_t abc[3]) {
+    ZK_ARGS(c, abc);
+    arena_reset(c);
+    return intersect_count(c, (const u64*)d_x, nx, (const u64*)d_y, ny, abc);
+}
+
+int zk_trim(zk_ctx* c, const uint64_t* d_kmers, const void* d_counts, int count_bits, uint64_t n, uint64_t lo, uint64_t hi,
+            uint64_t* d_ok, void* d_oc, uint64_t cap, uint64_t* n_out) {
+    ZK_ARGS(c, n_out && (count_bits == 32 || count_bits == 64));
+    arena_reset(c);
+    return trim(c, (const u64*)d_kmers, d_counts, count_bits, n, lo, hi, (u64*)d_ok, d_oc, cap, n_out);
+}
+
+int zk_synth_reads(zk_ctx* c, uint64_t seed, uint64_t first, uint64_t count, int L, uint64_t genome, uint32_t sub_thr,
+                   uint32_t n_thr, uint8_t* d_stream) {
+    ZK_ARGS(c, L >= 1 && (genome == 0 || genome >= (uint64_t)L));
+    if (count == 0) return ZK_OK;
+    SynthArgs a{seed, first, count, L, genome, sub_thr, n_thr};
+    hipLaunchKernelGGL(synth_kernel, dim3(grid_for(c, count * (uint64_t)(L + 1), 256 * 16)), dim3(256), 0, c->stream, a, d_stream);
+    ZK_HIP(c, hipGetLastError());
+    return ZK_OK;
+}
+
+int zk_checksum(zk_ctx* c, const uint64_t* d_kmers, const uint32_t* d_counts, uint64_t n, uint64_t sums[3]) {
+    ZK_ARGS(c, sums);
+    u64* d = c->d_scalars + 12;
+    ZK_HIP(c, hipMemsetAsync(d, 0, 3 * sizeof(u64), c->stream));
+    if (n) {
+        hipLaunchKernelGGL(checksum_kernel, dim3(grid_for(c, n, 256 * 8)), dim3(256), 0, c->stream, (const u64*)d_kmers, d_counts, (u64)n, d);
+        ZK_HIP(c, hipGetLastError());
+    }
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 12, d, 3 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 3; i++) sums[i] = c->h_scalars[12 + i];
+    return ZK_OK;
+}
+
+int zk_stream_checksum(zk_ctx* c, const uint8_t* d_stream, uint64_t n_bytes, int K, uint64_t sums[3]) {
+    ZK_ARGS(c, sums && K >= 1 && K <= 32 && (((uintptr_t)d_stream) & 15) == 0);
+    u64* d = c->d_scalars + 12;
+    ZK_HIP(c, hipMemsetAsync(d, 0, 3 * sizeof(u64), c->stream));
+    if (n_bytes) {
+        const u32 tiles = (u32)div_up(n_bytes, CS_TILE);
+        hipLaunchKernelGGL(stream_checksum_kernel, dim3(grid_for(c, tiles, 1)), dim3(CS_BLOCK), 0, c->stream, d_stream, (u64)n_bytes, K, tiles, d);
+        ZK_HIP(c, hipGetLastError());
+    }
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 12, d, 3 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 3; i++) sums[i] = c->h_scalars[12 + i];
+    return ZK_OK;
+}
+
+}  // extern "C"

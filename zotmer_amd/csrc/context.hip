@@ -1,0 +1,222 @@
+// context.hip -- zk_ctx: device, stream, workspace arena, look-back state, error reporting,
+// and the buffer-management entry points of the C-ABI (include/zotk.h).
+#include <stdarg.h>
+#include <string.h>
+
+#include "internal.hpp"
+
+namespace zk {
+
+int fail(zk_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->last_error = buf;
+    return code;
+}
+
+void arena_reset(zk_ctx* c) { c->arena_off = 0; }
+
+int arena_alloc(zk_ctx* c, uint64_t bytes, void** p) {
+    const uint64_t need = (bytes + 255) & ~255ull;
+    if (c->arena_off + need > c->arena_size) {
+        if (c->arena_off != 0)
+            return fail(c, ZK_ENOMEM, "workspace too small: %llu bytes in use, %llu more needed, %llu reserved (call zk_reserve)",
+                        (unsigned long long)c->arena_off, (unsigned long long)need, (unsigned long long)c->arena_size);
+        // nothing handed out yet in this call: safe to regrow
+        ZK_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->arena) { ZK_HIP(c, hipFree(c->arena)); c->arena = nullptr; c->arena_size = 0; }
+        ZK_HIP(c, hipMalloc((void**)&c->arena, need));
+        c->arena_size = need;
+    }
+    *p = c->arena + c->arena_off;
+    c->arena_off += need;
+    return ZK_OK;
+}
+
+// Make the arena at least `want` bytes (clamped to what the device can give); call before the
+// first arena_alloc of an API call.  `must` is the part the call cannot run without.
+int arena_require(zk_ctx* c, uint64_t want, uint64_t must) {
+    if (want <= c->arena_size) return ZK_OK;
+    if (c->arena_off != 0) return fail(c, ZK_EINTERNAL, "arena_require after arena_alloc");
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    size_t f = 0, t = 0;
+    ZK_HIP(c, hipMemGetInfo(&f, &t));
+    uint64_t avail = (uint64_t)((double)(f + c->arena_size) * 0.94);
+    uint64_t target = want < avail ? want : avail;
+    if (target < must) return fail(c, ZK_ENOMEM, "needs %llu bytes of workspace, the device can give %llu",
+                                   (unsigned long long)must, (unsigned long long)avail);
+    if (target <= c->arena_size) return ZK_OK;
+    if (c->arena) { ZK_HIP(c, hipFree(c->arena)); c->arena = nullptr; c->arena_size = 0; }
+    target = (target + 255) & ~255ull;
+    hipError_t e = hipMalloc((void**)&c->arena, target);
+    if (e != hipSuccess) return fail(c, ZK_ENOMEM, "hipMalloc(%llu) for the workspace failed: %s", (unsigned long long)target, hipGetErrorString(e));
+    c->arena_size = target;
+    return ZK_OK;
+}
+
+int lookback_begin(zk_ctx* c, uint64_t words, uint32_t tiles, u32* epoch, u32* ticket_base) {
+    if (words > c->status_words) {
+        ZK_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->status) { ZK_HIP(c, hipFree(c->status)); c->status = nullptr; c->status_words = 0; }
+        const uint64_t w = words + words / 8 + 1024;
+        ZK_HIP(c, hipMalloc((void**)&c->status, w * sizeof(u64)));
+        c->status_words = w;
+        c->epoch = 0;
+    }
+    if (c->epoch == 0 || c->epoch >= 31) {
+        ZK_HIP(c, hipMemsetAsync(c->status, 0, c->status_words * sizeof(u64), c->stream));
+        c->epoch = 0;
+    }
+    c->epoch++;
+    *epoch = c->epoch;
+    *ticket_base = c->ticket_base;
+    c->ticket_base += tiles;   // wraps with the device counter
+    return ZK_OK;
+}
+
+int check_device_error(zk_ctx* c) {
+    u32 e = 0;
+    ZK_HIP(c, hipMemcpyAsync(&e, c->d_err, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    if (e == 0) return ZK_OK;
+    ZK_HIP(c, hipMemsetAsync(c->d_err, 0, sizeof(u32), c->stream));
+    if (e & ZK_DERR_SPIN_TIMEOUT) {
+        // the ticket counter and status words are in an unknown state: start over
+        (void)hipMemsetAsync(c->d_ticket, 0, sizeof(u32), c->stream);
+        c->ticket_base = 0;
+        c->epoch = 0;
+        return fail(c, ZK_EINTERNAL, "device look-back spin limit reached (kernel bug or lost workgroup)");
+    }
+    if (e & ZK_DERR_CAPACITY) return fail(c, ZK_ENOSPC, "output does not fit the capacity given");
+    if (e & ZK_DERR_COUNT_OVERFLOW) return fail(c, ZK_EOVERFLOW, "a k-mer count does not fit the count type");
+    return fail(c, ZK_EINTERNAL, "device error word 0x%x", e);
+}
+
+}  // namespace zk
+
+using namespace zk;
+
+extern "C" {
+
+zk_ctx* zk_create(int device, uint64_t workspace_bytes) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    zk_ctx* c = new zk_ctx();
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    c->own_stream = ok;
+    ok = ok && hipMalloc((void**)&c->d_ticket, sizeof(u32)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_err, sizeof(u32)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_scalars, 64 * sizeof(u64)) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&c->h_scalars, 64 * sizeof(u64), hipHostMallocDefault) == hipSuccess;
+    ok = ok && hipMemset(c->d_ticket, 0, sizeof(u32)) == hipSuccess;
+    ok = ok && hipMemset(c->d_err, 0, sizeof(u32)) == hipSuccess;
+    ok = ok && hipMemset(c->d_scalars, 0, 64 * sizeof(u64)) == hipSuccess;
+    if (ok && workspace_bytes) {
+        ok = hipMalloc((void**)&c->arena, workspace_bytes) == hipSuccess;
+        if (ok) c->arena_size = workspace_bytes;
+    }
+    if (!ok) { zk_destroy(c); return nullptr; }
+    return c;
+}
+
+void zk_destroy(zk_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->arena) (void)hipFree(c->arena);
+    if (c->status) (void)hipFree(c->status);
+    if (c->d_ticket) (void)hipFree(c->d_ticket);
+    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->d_scalars) (void)hipFree(c->d_scalars);
+    if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* zk_last_error(zk_ctx* c) { return c ? c->last_error.c_str() : "no context (no MI355X visible, or bad device index)"; }
+
+int zk_set_stream(zk_ctx* c, void* hip_stream) {
+    if (!c) return ZK_EINVAL;
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
+    if (hip_stream) c->stream = (hipStream_t)hip_stream;
+    else {
+        ZK_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return ZK_OK;
+}
+
+void* zk_get_stream(zk_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int zk_sync(zk_ctx* c) {
+    if (!c) return ZK_EINVAL;
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+int zk_reserve(zk_ctx* c, uint64_t workspace_bytes) {
+    if (!c) return ZK_EINVAL;
+    if (workspace_bytes <= c->arena_size) return ZK_OK;
+    arena_reset(c);
+    void* p;
+    ZK_TRY(arena_alloc(c, workspace_bytes, &p));
+    arena_reset(c);
+    return ZK_OK;
+}
+
+int zk_mem_info(zk_ctx* c, uint64_t* free_bytes, uint64_t* total_bytes) {
+    if (!c) return ZK_EINVAL;
+    size_t f = 0, t = 0;
+    ZK_HIP(c, hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return ZK_OK;
+}
+
+int zk_alloc(zk_ctx* c, uint64_t bytes, void** dptr) {
+    if (!c || !dptr) return ZK_EINVAL;
+    *dptr = nullptr;
+    if (bytes == 0) bytes = 256;
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e != hipSuccess) return fail(c, ZK_ENOMEM, "hipMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+    return ZK_OK;
+}
+
+int zk_free(zk_ctx* c, void* dptr) {
+    if (!c) return ZK_EINVAL;
+    if (dptr) { ZK_HIP(c, hipStreamSynchronize(c->stream)); ZK_HIP(c, hipFree(dptr)); }
+    return ZK_OK;
+}
+
+int zk_upload(zk_ctx* c, void* dst_dev, const void* src_host, uint64_t bytes) {
+    if (!c) return ZK_EINVAL;
+    if (bytes == 0) return ZK_OK;
+    ZK_HIP(c, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+int zk_download(zk_ctx* c, void* dst_host, const void* src_dev, uint64_t bytes) {
+    if (!c) return ZK_EINVAL;
+    if (bytes == 0) return ZK_OK;
+    ZK_HIP(c, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
+}
+
+int zk_copy(zk_ctx* c, void* dst_dev, const void* src_dev, uint64_t bytes) {
+    if (!c) return ZK_EINVAL;
+    if (bytes == 0) return ZK_OK;
+    ZK_HIP(c, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return ZK_OK;
+}
+
+}  // extern "C"

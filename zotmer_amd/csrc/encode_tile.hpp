@@ -1,0 +1,89 @@
+// encode_tile.hpp -- the sliding-window 2-bit encoder, as a per-tile device routine.
+//
+// Reference semantics: basics.kmersList (zotmer/library/basics.py:303-347) with the base table
+// _nuc (:42-46): every position p of a sequence whose K bases p..p+K-1 are all in AaCcGgTtUu
+// yields x = the 2K-bit big-endian packing of those bases (A0 C1 G2 T/U3) and, on the other
+// strand, xb = rc(x); any other byte kills every window that overlaps it.
+//
+// Device input is a "base stream": the sequences of a batch, each followed by one byte that is
+// not a base ('\n').  A window can then never span two reads, so "window valid" is simply "K
+// valid bytes in a row" and no per-read offsets are read on the device.
+//
+// A tile of T stream positions is staged once: a workgroup loads T + 32 bytes with 16-byte
+// coalesced loads, converts them to a 2-bit packed image plus a validity bit image in LDS
+// (16 bases per 32-bit word, first base in the top bits), and every window is then ONE
+// funnel shift out of that image -- O(1) per window for any lane-to-position mapping, which
+// is what lets the radix sort's first pass and the digit histogram generate their keys
+// directly from the stream instead of reading an 8-byte-per-key array.
+#pragma once
+#include "common.hpp"
+
+namespace zk {
+
+// number of 32-bit image words for a tile of T positions: T/16 data chunks, two halo chunks
+// (K-1 <= 31 bytes) and one pad word so a window can always read four consecutive words
+template <int T> struct TileImage {
+    static constexpr int NCH = T / 16 + 3;
+    u32 codes[NCH];
+    u32 valid[NCH];
+};
+
+__device__ __forceinline__ void encode_chunk16(const u8* __restrict__ stream, u64 n_bytes, u64 off,
+                                               u32& codes, u32& vmask) {
+    u32 w[4] = {0, 0, 0, 0};
+    if (off + 16 <= n_bytes) {
+        uint4 q = *reinterpret_cast<const uint4*>(stream + off);
+        w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+    } else if (off < n_bytes) {
+        for (int b = 0; b < 16; b++) {
+            u32 c = (off + b < n_bytes) ? stream[off + b] : 0u;
+            w[b >> 2] |= c << (8 * (b & 3));
+        }
+    }
+    u32 cc = 0, vv = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            u32 c = (w[i] >> (8 * b)) & 0xffu;
+            u32 t = (c >> 1) & 3u;               // A0 C1 G3 T2 (also lower case, U == T)
+            u32 code = t ^ (t >> 1);             // A0 C1 G2 T3
+            u32 d = (c | 0x20u) - 0x61u;         // 'a' -> 0
+            u32 ok = (d <= 20u) ? ((0x180045u >> d) & 1u) : 0u;   // a c g t u
+            cc = (cc << 2) | code;
+            vv = (vv << 1) | ok;
+        }
+    }
+    codes = cc;
+    vmask = vv;     // 16 bits, first byte in bit 15
+}
+
+// Stage positions [t0, t0 + T) (+ halo) of the stream into `img`.  `stream` must be 16-byte
+// aligned and t0 a multiple of 16.  Ends with a workgroup barrier.
+template <int BLOCK, int T>
+__device__ __forceinline__ void stage_tile(const u8* __restrict__ stream, u64 n_bytes, u64 t0, TileImage<T>& img) {
+    for (int c = threadIdx.x; c < TileImage<T>::NCH; c += BLOCK) {
+        u32 cc, vv;
+        encode_chunk16(stream, n_bytes, t0 + 16ull * c, cc, vv);
+        img.codes[c] = cc;
+        img.valid[c] = vv;
+    }
+    __syncthreads();
+}
+
+// Window at tile-relative position p (0 <= p < T): returns true iff all K bases are valid.
+template <int T>
+__device__ __forceinline__ bool window_at(const TileImage<T>& img, int p, int K, u64& x) {
+    const int j = p >> 4;
+    const int s = p & 15;
+    const u64 a = ((u64)img.codes[j] << 32) | img.codes[j + 1];
+    const u64 b = ((u64)img.codes[j + 2] << 32) | img.codes[j + 3];
+    const u64 hi = s ? ((a << (2 * s)) | (b >> (64 - 2 * s))) : a;
+    x = hi >> (64 - 2 * K);
+    const u64 v = ((u64)img.valid[j] << 48) | ((u64)img.valid[j + 1] << 32) | ((u64)img.valid[j + 2] << 16) |
+                  (u64)img.valid[j + 3];
+    const u64 need = (K >= 64) ? ~0ull : ((1ull << K) - 1);
+    return ((v << s) >> (64 - K)) == need;
+}
+
+}  // namespace zk

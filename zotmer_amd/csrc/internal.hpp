@@ -1,0 +1,86 @@
+// internal.hpp -- host-side context shared by the libzotk translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/zotk.h"
+#include "common.hpp"
+
+struct zk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+
+    // workspace arena: a bump allocator reset at the start of every API call
+    char* arena = nullptr;
+    uint64_t arena_size = 0;
+    uint64_t arena_off = 0;
+
+    // decoupled look-back state (persistent: cleared once per 31 launches, see common.hpp)
+    u64* status = nullptr;
+    uint64_t status_words = 0;
+    u32 epoch = 0;
+    u32* d_ticket = nullptr;   // monotonically increasing tile ticket
+    u32 ticket_base = 0;
+
+    u32* d_err = nullptr;      // device error word
+    u64* d_scalars = nullptr;  // 64 device scalars for small results
+    u64* h_scalars = nullptr;  // pinned mirror
+
+    std::string last_error;
+};
+
+namespace zk {
+
+int fail(zk_ctx* c, int code, const char* fmt, ...);
+#define ZK_HIP(c, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return zk::fail((c), ZK_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+#define ZK_TRY(expr)             \
+    do {                         \
+        int r__ = (expr);        \
+        if (r__ != ZK_OK) return r__; \
+    } while (0)
+
+// arena
+void arena_reset(zk_ctx* c);
+int arena_alloc(zk_ctx* c, uint64_t bytes, void** p);   // 256-byte aligned; grows the arena when idle
+int arena_require(zk_ctx* c, uint64_t want, uint64_t must);
+// look-back state for one launch that needs `words` status words and `tiles` tickets
+int lookback_begin(zk_ctx* c, uint64_t words, uint32_t tiles, u32* epoch, u32* ticket_base);
+// read and clear the device error word (after a stream sync); maps it to a ZK_E* code
+int check_device_error(zk_ctx* c);
+
+static inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+// ---- launchers implemented in the kernel files (all asynchronous on c->stream) -------------
+// radix_sort.hip
+int sort_workspace_bytes(uint64_t n, bool pairs, uint64_t* bytes);
+int sort_keys(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** result);
+int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, u64** rk, u32** rv);
+// sort whose first pass generates the keys from a base stream (encode.hip + radix_sort.hip)
+struct StreamSrc { const u8* stream; uint64_t n_bytes; int K; int mode; };   // mode: ZK_KEYS_*
+int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,
+                uint64_t acgt[4], u64** result);
+// select.hip
+int trim(zk_ctx* c, const u64* keys, const void* cnts, int cbits, uint64_t n, u64 lo, u64 hi, u64* ok, void* oc,
+         uint64_t cap, uint64_t* n_out);
+int project_dedupe(zk_ctx* c, const u64* keys, uint64_t n, int shift, u64* out, uint64_t cap, uint64_t* n_out);
+int subsample(zk_ctx* c, const u64* keys, uint64_t n, u64 seed, double p, u64* out, uint64_t cap, uint64_t* n_out);
+int subsample_pairs(zk_ctx* c, u64* keys, u32* cnts, uint64_t n, u64 seed, double p, uint64_t* n_out);   // in place
+int encode_list(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int both, u64* out, uint64_t cap, uint64_t* n_out,
+                uint64_t acgt[4]);
+int rle(zk_ctx* c, const u64* sorted, uint64_t n, u64* uniq, u32* counts, uint64_t cap, uint64_t* n_unique);
+int count_hist(zk_ctx* c, const void* counts, int count_bits, uint64_t n, uint64_t* vals, uint64_t* freq,
+               uint64_t cap_bins, uint64_t* n_bins);
+// setops.hip
+int union_sum(zk_ctx* c, const u64* A, const void* cA, u64 nA, const u64* B, const void* cB, u64 nB, u64* ok, void* oc,
+              int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);
+int intersect_count(zk_ctx* c, const u64* A, u64 nA, const u64* B, u64 nB, uint64_t abc[3]);
+}  // namespace zk

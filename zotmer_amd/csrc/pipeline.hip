@@ -1,0 +1,174 @@
+// pipeline.hip -- the device-resident `zot kmerize` batch (zotmer/commands/kmerize.py:450-562)
+// and the k-way merge of `zot merge` (zotmer/commands/merge.py:165-253).
+//
+// kmerize, reference: reads(..., both=True) -> kmersList emits x AND rc(x) for every valid
+// window (commands/kmerize.py:490, library/reads.py:113-114); KmerAccumulator2 buffers them,
+// radix-sorts and run-length counts (:370-437).  The result is strand-symmetric:
+// count(x) == count(rc x), and a palindrome (x == rc x, even K only) is counted twice per window.
+//
+// Here (default, ZK_KMERIZE_CANONICAL): sort only ONE key per window, c = min(x, rc x) -- half
+// the sort volume --, run-length count it, then rebuild both strands exactly: the pairs
+// (rc c, n) are sorted by key and union-summed with (c, n); a palindrome meets itself there and
+// gets n + n, which is what two emissions per window give.  Any deterministic representative
+// would do because it never leaves the device.  ZK_KMERIZE_BOTH sorts both strands directly
+// (the literal reference path; kept as a cross-check and for tests).
+// -D (murmer subsample, :494-509) is a per-VALUE predicate, so it is applied to the counted set
+// instead of to every instance; acgt is taken before any filtering, as in the reference (:492-493).
+#include <string.h>
+
+#include <vector>
+
+#include "internal.hpp"
+
+namespace zk {
+
+__global__ void mirror_kernel(const u64* __restrict__ c, const u32* __restrict__ n, u64 m, int K, u64* __restrict__ r,
+                              u32* __restrict__ v) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (u64)gridDim.x * blockDim.x) {
+        r[i] = revcomp(K, c[i]);
+        v[i] = n[i];
+    }
+}
+
+__global__ void widen_kernel(const u32* __restrict__ in, u64* __restrict__ out, u64 m) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (u64)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
+static u32 ew_grid(zk_ctx* c, u64 n) {
+    u64 g = div_up(n, 256);
+    u64 mx = (u64)c->num_cus * 16;
+    return (u32)(g < mx ? (g ? g : 1) : mx);
+}
+
+int widen_counts(zk_ctx* c, const u32* in, u64* out, uint64_t n) {
+    if (n == 0) return ZK_OK;
+    hipLaunchKernelGGL(widen_kernel, dim3(ew_grid(c, n)), dim3(256), 0, c->stream, in, out, (u64)n);
+    ZK_HIP(c, hipGetLastError());
+    return ZK_OK;
+}
+
+int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, double p, uint64_t seed, u64* out_k, u32* out_c,
+            uint64_t cap, zk_kmerize_stats* st) {
+    memset(st, 0, sizeof *st);
+    if (K < 1 || K > 32) return fail(c, ZK_EINVAL, "K must be in 1..32 (got %d)", K);
+    if (n_bytes == 0) return ZK_OK;
+    const bool both = (flags & ZK_KMERIZE_BOTH) != 0;
+    const uint64_t cap_keys = both ? 2 * n_bytes : n_bytes;   // one window per stream byte at most
+    arena_reset(c);
+    const uint64_t slack = (1 << 20) + cap_keys / 16;
+    ZK_TRY(arena_require(c, 16 * cap_keys + (both ? 0 : 24 * cap_keys) + slack, 16 * cap_keys + slack));
+    u64 *buf_a, *buf_b;
+    ZK_TRY(arena_alloc(c, 8 * cap_keys, (void**)&buf_a));
+    ZK_TRY(arena_alloc(c, 8 * cap_keys, (void**)&buf_b));
+
+    StreamSrc src{stream, n_bytes, K, both ? ZK_KEYS_BOTH : ZK_KEYS_CANONICAL};
+    uint64_t n = 0;
+    u64* sorted = nullptr;
+    ZK_TRY(sort_stream(c, src, buf_a, buf_b, cap_keys, &n, st->acgt, &sorted));
+    st->n_windows = both ? n / 2 : n;
+    st->n_instances = both ? n : 2 * n;
+    uint64_t n_out = 0;
+    if (both) {
+        ZK_TRY(rle(c, sorted, n, out_k, out_c, cap, &n_out));
+        st->n_canonical = 0;
+    } else {
+        u64* other = (sorted == buf_a) ? buf_b : buf_a;
+        u32* cnt = (u32*)other;
+        uint64_t uc = 0;
+        ZK_TRY(rle(c, sorted, n, sorted, cnt, n, &uc));     // in place: sorted[0..uc) = distinct canonical k-mers
+        st->n_canonical = uc;
+        if (uc) {
+            u64 *rk, *rk2; u32 *rv, *rv2;
+            ZK_TRY(arena_alloc(c, 8 * uc, (void**)&rk));
+            ZK_TRY(arena_alloc(c, 8 * uc, (void**)&rk2));
+            ZK_TRY(arena_alloc(c, 4 * uc, (void**)&rv));
+            ZK_TRY(arena_alloc(c, 4 * uc, (void**)&rv2));
+            hipLaunchKernelGGL(mirror_kernel, dim3(ew_grid(c, uc)), dim3(256), 0, c->stream, sorted, cnt, (u64)uc, K, rk, rv);
+            ZK_HIP(c, hipGetLastError());
+            u64* sk; u32* sv;
+            ZK_TRY(sort_pairs(c, rk, rk2, rv, rv2, uc, 2 * K, &sk, &sv));
+            ZK_TRY(union_sum(c, sorted, cnt, uc, sk, sv, uc, out_k, out_c, 32, cap, &n_out, nullptr));
+        }
+    }
+    if (flags & ZK_KMERIZE_SUBSAMPLE) {
+        uint64_t kept = 0;
+        ZK_TRY(subsample_pairs(c, out_k, out_c, n_out, seed, p, &kept));
+        n_out = kept;
+    }
+    st->n_unique = n_out;
+    return check_device_error(c);
+}
+
+// k-way union-sum as a balanced tree of 2-way passes; counts are 64-bit.
+// ins: k device arrays (keys, counts, n).  The result lands in (out_k, out_c).
+int merge_many(zk_ctx* c, int k, const u64* const* keys, const u64* const* cnts, const uint64_t* ns, u64* out_k, u64* out_c,
+               uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]) {
+    *n_out = 0;
+    if (acgt_w) acgt_w[0] = acgt_w[1] = acgt_w[2] = acgt_w[3] = 0;
+    if (k <= 0) return ZK_OK;
+    arena_reset(c);
+    uint64_t total = 0;
+    for (int i = 0; i < k; i++) total += ns[i];
+    if (k == 1) {
+        // union with the empty set: a plain copy that also yields the count-weighted acgt
+        return union_sum(c, keys[0], cnts[0], ns[0], keys[0], cnts[0], 0, out_k, out_c, 64, cap, n_out, acgt_w);
+    }
+    // two ping-pong regions, each able to hold every intermediate list of one level
+    const uint64_t slack = 1 << 20;
+    const uint64_t rbytes = 16 * total + 512ull * k;
+    const uint64_t need = 2 * rbytes + total / 8 + 8192ull * k + slack;   // + merge-path partitions
+    ZK_TRY(arena_require(c, need, need));
+    struct L { const u64* k; const u64* c; uint64_t n; };
+    std::vector<L> va(k), vb(k);
+    L* cur = va.data();
+    L* nxt = vb.data();
+    for (int i = 0; i < k; i++) cur[i] = L{keys[i], cnts[i], ns[i]};
+    char* region[2];
+    ZK_TRY(arena_alloc(c, rbytes, (void**)&region[0]));
+    ZK_TRY(arena_alloc(c, rbytes, (void**)&region[1]));
+    auto in_regions = [&](const void* q) {
+        const char* b = (const char*)q;
+        return (b >= region[0] && b < region[0] + rbytes) || (b >= region[1] && b < region[1] + rbytes);
+    };
+    int m = k, level = 0;
+    while (m > 1) {
+        const bool last = (m == 2);
+        char* base = region[level & 1];
+        uint64_t off = 0;
+        int o = 0;
+        for (int i = 0; i + 1 < m; i += 2) {
+            const uint64_t cap2 = cur[i].n + cur[i + 1].n;
+            u64* ok; u64* oc; uint64_t capo;
+            if (last) { ok = out_k; oc = out_c; capo = cap; }
+            else {
+                ok = (u64*)(base + off); off += (8 * cap2 + 255) & ~255ull;
+                oc = (u64*)(base + off); off += (8 * cap2 + 255) & ~255ull;
+                capo = cap2;
+            }
+            uint64_t no = 0;
+            ZK_TRY(union_sum(c, cur[i].k, cur[i].c, cur[i].n, cur[i + 1].k, cur[i + 1].c, cur[i + 1].n, ok, oc, 64, capo, &no,
+                             last ? acgt_w : nullptr));
+            nxt[o++] = L{ok, oc, no};
+        }
+        if (m & 1) {
+            // the odd list sits out this level; if it lives in a ping-pong region the level after
+            // next would overwrite it, so move it along with this level's outputs
+            L x = cur[m - 1];
+            if (in_regions(x.k)) {
+                u64* ok = (u64*)(base + off); off += (8 * x.n + 255) & ~255ull;
+                u64* oc = (u64*)(base + off); off += (8 * x.n + 255) & ~255ull;
+                ZK_HIP(c, hipMemcpyAsync(ok, x.k, 8 * x.n, hipMemcpyDeviceToDevice, c->stream));
+                ZK_HIP(c, hipMemcpyAsync(oc, x.c, 8 * x.n, hipMemcpyDeviceToDevice, c->stream));
+                x.k = ok; x.c = oc;
+            }
+            nxt[o++] = x;
+        }
+        L* t = cur; cur = nxt; nxt = t;
+        m = o;
+        level++;
+    }
+    *n_out = cur[0].n;
+    return ZK_OK;
+}
+
+}  // namespace zk

@@ -1,0 +1,480 @@
+// radix_sort.hip -- K3: least-significant-digit radix sort of 64-bit k-mers on gfx950.
+//
+// Replaces misc.radix_sort (zotmer/library/misc.py:400-424) as called from
+// KmerAccumulator2.flush (zotmer/commands/kmerize.py:412-417): ascending order of the 2K
+// significant bits.
+//
+// Shape ("onesweep"): ONE histogram kernel counts every pass's digits up front; then each pass
+// reads every key once and writes it once.  Inside a pass a workgroup owns a tile of
+// BLOCK*ITEMS keys held in registers in wave-striped order, ranks them with wave64 ballots
+// (match-any over the digit bits + mbcnt), learns where its keys go from the tiles before it
+// through a decoupled look-back (common.hpp), regroups the tile by digit in LDS and writes
+// digit-contiguous runs, so stores are coalesced per run.  Tiles are numbered by a ticket, not
+// by blockIdx, so the look-back never waits for a workgroup that has not started.
+//
+// The first pass can take its keys from a BASE STREAM instead of an array (SRC_STREAM): the
+// tile is encoded in LDS (encode_tile.hpp) and the keys never exist in HBM unsorted.  That
+// removes the 8 B/key write + 8 B/key read an unfused encode would cost, and lets invalid
+// windows vanish without a compaction pass (dead items are simply not ranked).
+//
+// Algorithmic bytes per key per pass: 8 read + 8 written (+4/+4 with a 32-bit payload).
+#include "internal.hpp"
+#include "encode_tile.hpp"
+
+namespace zk {
+
+constexpr int SORT_BLOCK = 512;
+constexpr int SORT_ITEMS = 16;
+constexpr int SORT_RBITS = 8;
+constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;
+constexpr int SORT_RADIX = 1 << SORT_RBITS;
+constexpr int MAX_PASSES = 8;
+
+enum { SRC_ARRAY = 0, SRC_STREAM = 1 };
+
+struct PassPlan {
+    int passes;
+    int shift[MAX_PASSES];
+    int bits[MAX_PASSES];
+};
+
+static PassPlan make_plan(int key_bits) {
+    PassPlan p;
+    if (key_bits < 1) key_bits = 1;
+    if (key_bits > 64) key_bits = 64;
+    p.passes = (key_bits + SORT_RBITS - 1) / SORT_RBITS;
+    int base = key_bits / p.passes, rem = key_bits % p.passes, s = 0;
+    for (int i = 0; i < MAX_PASSES; i++) { p.shift[i] = 0; p.bits[i] = 0; }
+    for (int i = 0; i < p.passes; i++) {
+        p.bits[i] = base + (i < rem ? 1 : 0);
+        p.shift[i] = s;
+        s += p.bits[i];
+    }
+    return p;
+}
+
+struct SortArgs {
+    // array source
+    const u64* kin;
+    const u32* vin;
+    u64 n;
+    // stream source
+    const u8* stream;
+    u64 n_bytes;
+    int K;
+    int mode;
+    // outputs
+    u64* kout;
+    u32* vout;
+    // digit of this pass
+    int shift;
+    int bits;
+    const u64* ghist;   // [RADIX] exclusive prefix of this pass's digit over all keys
+    // look-back
+    u64* status;
+    u32* ticket;
+    u32 ticket_base;
+    u32 epoch;
+    u32* err;
+};
+
+// Generate this thread's ITEMS keys of tile `tile` in wave-striped order.
+//   array : key i of lane l of wave w is element  tile*TILE + w*64*ITEMS + i*64 + l
+//   stream: the tile covers POS stream positions (POS = TILE, or TILE/2 when both strands are
+//           emitted: items [0, ITEMS/2) are x, items [ITEMS/2, ITEMS) the matching rc(x))
+// acgt (COUNT only): four 8-bit counters packed in a word, acgt[b] in byte b -- at most 2*ITEMS
+// increments per call, so they cannot carry into each other.
+template <int BLOCK, int ITEMS, int SRC, bool PAIRS, bool COUNT>
+__device__ __forceinline__ u32 load_tile(const SortArgs& a, u32 tile, TileImage<BLOCK * ITEMS>* img,
+                                         u64 (&key)[ITEMS], u32 (&val)[ITEMS], u32& acgt) {
+    static_assert(2 * ITEMS < 256, "packed acgt counters are 8 bits");
+    constexpr int TILE = BLOCK * ITEMS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 live = 0;
+    if (SRC == SRC_ARRAY) {
+        const u64 base = (u64)tile * TILE + (u64)wave * (64 * ITEMS) + lane;
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const u64 idx = base + (u64)i * 64;
+            const bool ok = idx < a.n;
+            key[i] = ok ? a.kin[idx] : 0ull;
+            if (PAIRS) val[i] = ok ? a.vin[idx] : 0u;
+            live |= (ok ? 1u : 0u) << i;
+        }
+    } else {
+        const bool both = (a.mode == ZK_KEYS_BOTH);
+        const int pos_per_tile = both ? TILE / 2 : TILE;
+        const u64 t0 = (u64)tile * pos_per_tile;
+        // stage only what this tile needs
+        for (int c = threadIdx.x; c < pos_per_tile / 16 + 3; c += BLOCK) {
+            u32 cc, vv;
+            encode_chunk16(a.stream, a.n_bytes, t0 + 16ull * c, cc, vv);
+            img->codes[c] = cc;
+            img->valid[c] = vv;
+        }
+        __syncthreads();
+        const int K = a.K;
+        if (both) {
+            constexpr int H = ITEMS / 2;
+#pragma unroll
+            for (int i = 0; i < H; i++) {
+                const int p = wave * (64 * H) + i * 64 + lane;
+                u64 x;
+                const bool ok = window_at(*img, p, K, x);
+                const u64 xb = revcomp(K, x);
+                key[i] = x;
+                key[i + H] = xb;
+                live |= (ok ? 1u : 0u) << i;
+                live |= (ok ? 1u : 0u) << (i + H);
+                if (COUNT && ok) acgt += (1u << (8 * (u32)(x & 3))) + (1u << (8 * (u32)(xb & 3)));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const int p = wave * (64 * ITEMS) + i * 64 + lane;
+                u64 x;
+                const bool ok = window_at(*img, p, K, x);
+                const u64 xb = revcomp(K, x);
+                key[i] = (a.mode == ZK_KEYS_CANONICAL) ? (x < xb ? x : xb) : x;
+                live |= (ok ? 1u : 0u) << i;
+                if (COUNT && ok) acgt += (1u << (8 * (u32)(x & 3))) + (1u << (8 * (u32)(xb & 3)));
+            }
+        }
+    }
+    return live;
+}
+
+// ---------------------------------------------------------------------------------------
+// up-front histogram of every pass's digit (one read of the keys, or of the stream)
+// ---------------------------------------------------------------------------------------
+struct HistArgs {
+    SortArgs src;        // only the source fields are used
+    PassPlan plan;
+    u64* ghist;          // [MAX_PASSES][RADIX], zeroed by the host
+    u64* acgt;           // [4] or null
+    u32 tiles;
+};
+
+template <int BLOCK, int ITEMS, int SRC>
+__global__ __launch_bounds__(BLOCK) void hist_kernel(HistArgs h) {
+    constexpr int TILE = BLOCK * ITEMS;
+    __shared__ u32 bins[MAX_PASSES][SORT_RADIX];
+    __shared__ TileImage<TILE> img;
+    for (int i = threadIdx.x; i < MAX_PASSES * SORT_RADIX; i += BLOCK) (&bins[0][0])[i] = 0;
+    u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    __syncthreads();
+    for (u32 tile = blockIdx.x; tile < h.tiles; tile += gridDim.x) {
+        u64 key[ITEMS];
+        u32 val[ITEMS];
+        u32 pk = 0;
+        u32 live = load_tile<BLOCK, ITEMS, SRC, false, SRC == SRC_STREAM>(h.src, tile, &img, key, val, pk);
+        a0 += pk & 0xffu; a1 += (pk >> 8) & 0xffu; a2 += (pk >> 16) & 0xffu; a3 += pk >> 24;
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            if ((live >> i) & 1u) {
+                for (int p = 0; p < h.plan.passes; p++) {
+                    u32 d = (u32)(key[i] >> h.plan.shift[p]) & ((1u << h.plan.bits[p]) - 1u);
+                    atomicAdd(&bins[p][d], 1u);
+                }
+            }
+        }
+        if (SRC == SRC_STREAM) __syncthreads();   // img is restaged by the next iteration
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < h.plan.passes * SORT_RADIX; i += BLOCK) {
+        u32 v = (&bins[0][0])[i];
+        if (v) atomicAdd(&h.ghist[i], (u64)v);
+    }
+    if (h.acgt) {
+        a0 = wave_sum_u32(a0); a1 = wave_sum_u32(a1); a2 = wave_sum_u32(a2); a3 = wave_sum_u32(a3);
+        if ((threadIdx.x & 63) == 0) {
+            if (a0) atomicAdd(&h.acgt[0], (u64)a0);
+            if (a1) atomicAdd(&h.acgt[1], (u64)a1);
+            if (a2) atomicAdd(&h.acgt[2], (u64)a2);
+            if (a3) atomicAdd(&h.acgt[3], (u64)a3);
+        }
+    }
+}
+
+// exclusive prefix over the digits of every pass, in place; total key count to *n_out
+__global__ void hist_scan_kernel(u64* ghist, int passes, u64* n_out) {
+    __shared__ u64 wsum[SORT_RADIX / 64];
+    const int d = threadIdx.x;   // blockDim.x == RADIX
+    for (int p = 0; p < passes; p++) {
+        u64 v = ghist[p * SORT_RADIX + d];
+        u64 inc = wave_incl_scan_u64(v);
+        if ((d & 63) == 63) wsum[d >> 6] = inc;
+        __syncthreads();
+        u64 off = 0;
+        for (int w = 0; w < (d >> 6); w++) off += wsum[w];
+        ghist[p * SORT_RADIX + d] = off + inc - v;
+        if (p == 0 && d == SORT_RADIX - 1) *n_out = off + inc;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// one pass
+// ---------------------------------------------------------------------------------------
+template <int BLOCK, int ITEMS, int SRC, bool PAIRS>
+struct PassSmem {
+    static constexpr int TILE = BLOCK * ITEMS;
+    static constexpr int NW = BLOCK / 64;
+    union {
+        u64 exch[TILE];
+        TileImage<TILE> img;
+    };
+    u32 cnt[NW][SORT_RADIX];
+    u32 digit_off[SORT_RADIX];
+    u64 gbase[SORT_RADIX];
+    u32 wsum[NW];
+    u32 ticket;
+    u32 total_live;
+};
+
+template <int BLOCK, int ITEMS, int SRC, bool PAIRS>
+__global__ __launch_bounds__(BLOCK) void pass_kernel(SortArgs a) {
+    constexpr int NW = BLOCK / 64;
+    static_assert(SORT_RADIX <= BLOCK, "one digit per thread");
+    __shared__ PassSmem<BLOCK, ITEMS, SRC, PAIRS> sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    const u32 tile = take_ticket(a.ticket, &sm.ticket) - a.ticket_base;
+
+    u64 key[ITEMS];
+    u32 val[ITEMS];
+    u32 unused = 0;
+    const u32 live = load_tile<BLOCK, ITEMS, SRC, PAIRS, false>(a, tile, &sm.img, key, val, unused);
+
+    // ---- rank inside the wave ------------------------------------------------------------
+    u32* mycnt = sm.cnt[wave];
+    for (int d = lane; d < SORT_RADIX; d += 64) mycnt[d] = 0;
+    __syncthreads();
+    const u32 dmask = (1u << a.bits) - 1u;
+    u32 rank[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const bool lv = (live >> i) & 1u;
+        const u32 d = (u32)(key[i] >> a.shift) & dmask;
+        u64 peers = __ballot(lv);
+#pragma unroll
+        for (int b = 0; b < SORT_RBITS; b++) {
+            if (b < a.bits) {
+                const bool bit = (d >> b) & 1u;
+                const u64 m = __ballot(bit);
+                peers &= bit ? m : ~m;
+            }
+        }
+        const u32 below = popc_below(peers);
+        const u32 npeer = (u32)__popcll(peers);
+        const u32 pre = lv ? mycnt[d] : 0u;
+        rank[i] = pre + below;
+        if (lv && below == npeer - 1) mycnt[d] = pre + npeer;   // highest peer lane updates
+    }
+    __syncthreads();
+
+    // ---- per digit: exclusive scan over the waves, tile total ---------------------------------
+    u32 tile_count = 0;
+    if (tid < SORT_RADIX) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            u32 t = sm.cnt[w][tid];
+            sm.cnt[w][tid] = tile_count;
+            tile_count += t;
+        }
+    }
+    // exclusive scan of tile_count over the digits (threads >= RADIX hold 0)
+    u32 inc = wave_incl_scan_u32(tile_count);
+    if (lane == 63) sm.wsum[wave] = inc;
+    __syncthreads();
+    u32 woff = 0;
+    for (int w = 0; w < wave; w++) woff += sm.wsum[w];
+    const u32 dig_excl = woff + inc - tile_count;
+    if (tid == BLOCK - 1) sm.total_live = woff + inc;
+
+    // ---- decoupled look-back, one chain per digit ----------------------------------------------
+    if (tid < SORT_RADIX) {
+        u64* st = a.status + (u64)tile * SORT_RADIX + tid;
+        u64 excl = 0;
+        if (tile == 0) {
+            st_agent(st, st_pack(ZK_ST_INCLUSIVE, a.epoch, tile_count));
+        } else {
+            st_agent(st, st_pack(ZK_ST_PARTIAL, a.epoch, tile_count));
+            const u64* q = st - SORT_RADIX;
+            for (u32 t = tile; t > 0; t--, q -= SORT_RADIX) {
+                u64 w = ld_agent(q);
+                int spins = 0;
+                while (st_state(w, a.epoch) == 0) {
+                    if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    w = ld_agent(q);
+                }
+                excl += w & ZK_ST_VALUE_MASK;
+                if (st_state(w, a.epoch) != ZK_ST_PARTIAL) break;   // INCLUSIVE (or gave up)
+            }
+            st_agent(st, st_pack(ZK_ST_INCLUSIVE, a.epoch, excl + tile_count));
+        }
+        sm.digit_off[tid] = dig_excl;
+        sm.gbase[tid] = a.ghist[tid] + excl - dig_excl;
+    }
+    __syncthreads();
+
+    // ---- regroup the tile by digit in LDS ---------------------------------------------------
+    u32 lpos[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const u32 d = (u32)(key[i] >> a.shift) & dmask;
+        lpos[i] = sm.digit_off[d] + sm.cnt[wave][d] + rank[i];
+        if ((live >> i) & 1u) sm.exch[lpos[i]] = key[i];
+    }
+    __syncthreads();
+    const u32 total = sm.total_live;
+    u64 gpos[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const u32 s = tid + i * BLOCK;
+        gpos[i] = ~0ull;
+        if (s < total) {
+            const u64 k = sm.exch[s];
+            const u32 d = (u32)(k >> a.shift) & dmask;
+            gpos[i] = sm.gbase[d] + s;
+            a.kout[gpos[i]] = k;
+        }
+    }
+    if (PAIRS) {
+        __syncthreads();
+        u32* exv = reinterpret_cast<u32*>(sm.exch);
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++)
+            if ((live >> i) & 1u) exv[lpos[i]] = val[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const u32 s = tid + i * BLOCK;
+            if (s < total) a.vout[gpos[i]] = exv[s];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+static u32 tiles_for(const SortArgs& a, int src) {
+    if (src == SRC_ARRAY) return (u32)div_up(a.n, SORT_TILE);
+    const u64 pos = (a.mode == ZK_KEYS_BOTH) ? SORT_TILE / 2 : SORT_TILE;
+    return (u32)div_up(a.n_bytes, pos);
+}
+
+template <int SRC, bool PAIRS>
+static int launch_pass(zk_ctx* c, SortArgs a) {
+    const u32 tiles = tiles_for(a, SRC);
+    if (tiles == 0) return ZK_OK;
+    ZK_TRY(lookback_begin(c, (uint64_t)tiles * SORT_RADIX, tiles, &a.epoch, &a.ticket_base));
+    a.status = c->status;
+    a.ticket = c->d_ticket;
+    a.err = c->d_err;
+    hipLaunchKernelGGL((pass_kernel<SORT_BLOCK, SORT_ITEMS, SRC, PAIRS>), dim3(tiles), dim3(SORT_BLOCK), 0, c->stream, a);
+    ZK_HIP(c, hipGetLastError());
+    return ZK_OK;
+}
+
+template <int SRC>
+static int launch_hist(zk_ctx* c, const SortArgs& src, const PassPlan& plan, u64* ghist, u64* acgt, u64* d_n) {
+    HistArgs h;
+    h.src = src;
+    h.plan = plan;
+    h.ghist = ghist;
+    h.acgt = acgt;
+    h.tiles = tiles_for(src, SRC);
+    ZK_HIP(c, hipMemsetAsync(ghist, 0, sizeof(u64) * MAX_PASSES * SORT_RADIX, c->stream));
+    if (acgt) ZK_HIP(c, hipMemsetAsync(acgt, 0, sizeof(u64) * 4, c->stream));
+    u32 grid = h.tiles < (u32)(c->num_cus * 8) ? h.tiles : (u32)(c->num_cus * 8);
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL((hist_kernel<SORT_BLOCK, SORT_ITEMS, SRC>), dim3(grid), dim3(SORT_BLOCK), 0, c->stream, h);
+    ZK_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(hist_scan_kernel, dim3(1), dim3(SORT_RADIX), 0, c->stream, ghist, plan.passes, d_n);
+    ZK_HIP(c, hipGetLastError());
+    return ZK_OK;
+}
+
+int sort_keys(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** result) {
+    *result = keys;
+    if (n == 0) return ZK_OK;
+    PassPlan plan = make_plan(key_bits);
+    u64* ghist;
+    ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * SORT_RADIX, (void**)&ghist));
+    SortArgs a = {};
+    a.kin = keys; a.n = n;
+    ZK_TRY(launch_hist<SRC_ARRAY>(c, a, plan, ghist, nullptr, c->d_scalars + 8));
+    u64* in = keys; u64* out = alt;
+    for (int p = 0; p < plan.passes; p++) {
+        a.kin = in; a.kout = out; a.shift = plan.shift[p]; a.bits = plan.bits[p];
+        a.ghist = ghist + p * SORT_RADIX;
+        ZK_TRY((launch_pass<SRC_ARRAY, false>(c, a)));
+        u64* t = in; in = out; out = t;
+    }
+    *result = in;
+    return ZK_OK;
+}
+
+int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, u64** rk, u32** rv) {
+    *rk = keys; *rv = vals;
+    if (n == 0) return ZK_OK;
+    PassPlan plan = make_plan(key_bits);
+    u64* ghist;
+    ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * SORT_RADIX, (void**)&ghist));
+    SortArgs a = {};
+    a.kin = keys; a.n = n;
+    ZK_TRY(launch_hist<SRC_ARRAY>(c, a, plan, ghist, nullptr, c->d_scalars + 8));
+    u64* in = keys; u64* out = alt; u32* vi = vals; u32* vo = valt;
+    for (int p = 0; p < plan.passes; p++) {
+        a.kin = in; a.kout = out; a.vin = vi; a.vout = vo; a.shift = plan.shift[p]; a.bits = plan.bits[p];
+        a.ghist = ghist + p * SORT_RADIX;
+        ZK_TRY((launch_pass<SRC_ARRAY, true>(c, a)));
+        u64* t = in; in = out; out = t;
+        u32* tv = vi; vi = vo; vo = tv;
+    }
+    *rk = in; *rv = vi;
+    return ZK_OK;
+}
+
+// Sort the k-mers of a base stream without ever storing them unsorted: histogram and first pass
+// read the stream, the remaining passes ping-pong between buf_a and buf_b (cap keys each).
+int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,
+                uint64_t acgt[4], u64** result) {
+    *result = buf_a;
+    *n_keys = 0;
+    if (acgt) acgt[0] = acgt[1] = acgt[2] = acgt[3] = 0;
+    if (src.n_bytes == 0) return ZK_OK;
+    if ((uintptr_t)src.stream & 15) return fail(c, ZK_EINVAL, "base stream must be 16-byte aligned");
+    PassPlan plan = make_plan(2 * src.K);
+    u64* ghist;
+    ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * SORT_RADIX, (void**)&ghist));
+    SortArgs a = {};
+    a.stream = src.stream; a.n_bytes = src.n_bytes; a.K = src.K; a.mode = src.mode;
+    u64* d_acgt = c->d_scalars + 0;
+    u64* d_n = c->d_scalars + 8;
+    ZK_TRY(launch_hist<SRC_STREAM>(c, a, plan, ghist, d_acgt, d_n));
+    // the number of live keys decides the grids of the array passes: one small readback
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(u64) * 16, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    const uint64_t n = c->h_scalars[8];
+    if (acgt) for (int b = 0; b < 4; b++) acgt[b] = c->h_scalars[b];
+    *n_keys = n;
+    if (n > cap) return fail(c, ZK_ENOSPC, "sort buffers hold %llu keys, the stream has %llu", (unsigned long long)cap, (unsigned long long)n);
+    if (n == 0) return ZK_OK;
+    a.kout = buf_a; a.shift = plan.shift[0]; a.bits = plan.bits[0]; a.ghist = ghist;
+    ZK_TRY((launch_pass<SRC_STREAM, false>(c, a)));
+    u64* in = buf_a; u64* out = buf_b;
+    a.n = n;
+    for (int p = 1; p < plan.passes; p++) {
+        a.kin = in; a.kout = out; a.shift = plan.shift[p]; a.bits = plan.bits[p];
+        a.ghist = ghist + p * SORT_RADIX;
+        ZK_TRY((launch_pass<SRC_ARRAY, false>(c, a)));
+        u64* t = in; in = out; out = t;
+    }
+    *result = in;
+    return ZK_OK;
+}
+
+}  // namespace zk

@@ -1,0 +1,437 @@
+// select.hip -- order-preserving stream compaction kernels built on wave64 ballots:
+//   K4  run-length count of a sorted k-mer array            (kmerize.merge, commands/kmerize.py:41-132)
+//   K7  histogram of the counts                             (commands/kmerize.py:543-545, merge.py:88-92)
+//   K8  prefix projection + adjacent dedupe                 (Measure.prep, commands/dist.py:43-49)
+//   K10 count filter                                        (trim.trim, commands/trim.py:54-62)
+//   K2  murmer subsample                                    (basics.sub, library/basics.py:252-259;
+//                                                            caller commands/kmerize.py:494-509)
+//   K1  encode to a list in reference order                 (basics.kmersList, library/basics.py:303-347)
+//
+// Common shape: a workgroup owns a tile of BLOCK*ITEMS consecutive elements in wave-striped
+// order (row i of wave w = 64 consecutive elements, one per lane).  The keep/head flag of a row
+// is one __ballot; a lane's output slot is  tile base + wave base + popcounts of earlier rows
+// + mbcnt of its own row -- no LDS scan over elements.  The tile base comes from a decoupled
+// look-back over the tiles (common.hpp).  Kept lanes of a row write consecutive addresses.
+//
+// Algorithmic bytes: one read of the input, one write of what survives.
+#include <algorithm>
+#include <vector>
+
+#include "internal.hpp"
+#include "encode_tile.hpp"
+
+namespace zk {
+
+constexpr int SEL_BLOCK = 256;
+constexpr int SEL_ITEMS = 8;
+constexpr int SEL_TILE = SEL_BLOCK * SEL_ITEMS;
+constexpr int SEL_NW = SEL_BLOCK / 64;
+
+struct SelState {
+    u64* status;
+    u32* ticket;
+    u32 ticket_base;
+    u32 epoch;
+    u32* err;
+    u64* d_total;   // total number of outputs (written by the last tile)
+    u32 tiles;
+};
+
+struct SelSmem {
+    u32 wtot[SEL_NW];
+    u64 tile_excl;
+    u32 ticket;
+};
+
+// Returns the global output offset of this WAVE's first kept element; *tile_total gets the
+// tile's number of kept elements.  All threads of the workgroup must call it.
+__device__ __forceinline__ u64 select_wave_base(SelSmem& sm, const SelState& st, u32 tile, u32 wave_total, u32* tile_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) sm.wtot[wave] = wave_total;
+    __syncthreads();
+    u32 wex = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SEL_NW; w++) {
+        if (w < wave) wex += sm.wtot[w];
+        tot += sm.wtot[w];
+    }
+    if (wave == 0) {
+        u64 ex = lookback_exclusive(st.status, tile, tot, st.epoch, st.err);
+        if (lane == 0) {
+            sm.tile_excl = ex;
+            if (tile == st.tiles - 1) *st.d_total = ex + tot;
+        }
+    }
+    __syncthreads();
+    *tile_total = tot;
+    return sm.tile_excl + wex;
+}
+
+// ---------------------------------------------------------------------------------------
+// K4: run-length count.  uniq[j], counts[j] for the j-th distinct key of a sorted array.
+// A run that crosses a tile boundary is finished by rle_fixup_kernel: every tile records how
+// many of its leading elements continue the previous tile's last run.
+// ---------------------------------------------------------------------------------------
+struct RleSmem {
+    SelSmem sel;
+    u64 hkey[SEL_TILE];
+    u32 hidx[SEL_TILE];
+};
+
+// `uniq` may alias `keys` (in-place): a tile learns its output offset only after every earlier
+// tile has loaded its inputs, outputs never land beyond the tile's own input range, and the one
+// neighbour element a later tile may still read can only be overwritten with its own value.
+__global__ __launch_bounds__(SEL_BLOCK) void rle_kernel(const u64* keys, u64 n, u64* uniq,
+                                                        u32* __restrict__ counts, u64 cap, u32* __restrict__ lead,
+                                                        SelState st) {
+    __shared__ RleSmem sm;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 tile = take_ticket(st.ticket, &sm.sel.ticket) - st.ticket_base;
+    const u64 tile_base = (u64)tile * SEL_TILE;
+    const u64 base = tile_base + (u64)wave * (64 * SEL_ITEMS);
+
+    u64 k[SEL_ITEMS];
+    u64 hm[SEL_ITEMS];
+    u32 wave_total = 0;
+#pragma unroll
+    for (int i = 0; i < SEL_ITEMS; i++) {
+        const u64 idx = base + (u64)i * 64 + lane;
+        k[i] = (idx < n) ? keys[idx] : 0ull;
+    }
+#pragma unroll
+    for (int i = 0; i < SEL_ITEMS; i++) {
+        const u64 idx = base + (u64)i * 64 + lane;
+        u64 prev = __shfl_up(k[i], 1, 64);
+        if (i > 0) {
+            const u64 last = __shfl(k[i - 1], 63, 64);   // lane 63 of the previous row
+            if (lane == 0) prev = last;
+        } else if (lane == 0) {
+            prev = (idx > 0 && idx < n) ? keys[idx - 1] : 0ull;   // element before the wave's segment
+        }
+        const bool head = (idx < n) && (idx == 0 || k[i] != prev);
+        hm[i] = __ballot(head);
+        wave_total += (u32)__popcll(hm[i]);
+    }
+    u32 tile_total;
+    const u64 wbase = select_wave_base(sm.sel, st, tile, wave_total, &tile_total);
+    const u64 tile_excl = sm.sel.tile_excl;
+    // stage (key, tile-relative index) of every head in output order
+    u32 row_off = (u32)(wbase - tile_excl);
+#pragma unroll
+    for (int i = 0; i < SEL_ITEMS; i++) {
+        if ((hm[i] >> lane) & 1ull) {
+            const u32 q = row_off + popc_below(hm[i]);
+            sm.hkey[q] = k[i];
+            sm.hidx[q] = (u32)(wave * (64 * SEL_ITEMS) + i * 64 + lane);
+        }
+        row_off += (u32)__popcll(hm[i]);
+    }
+    __syncthreads();
+    const u64 rem = n - tile_base;
+    const u32 tile_len = rem < (u64)SEL_TILE ? (u32)rem : (u32)SEL_TILE;
+    for (u32 q = threadIdx.x; q < tile_total; q += SEL_BLOCK) {
+        const u32 end = (q + 1 < tile_total) ? sm.hidx[q + 1] : tile_len;
+        const u64 pos = tile_excl + q;
+        if (pos < cap) {
+            uniq[pos] = sm.hkey[q];
+            counts[pos] = end - sm.hidx[q];
+        }
+    }
+    if (threadIdx.x == 0) {
+        lead[tile] = tile_total ? sm.hidx[0] : tile_len;
+        if (tile == st.tiles - 1 && tile_excl + tile_total > cap) atomicOr(st.err, ZK_DERR_CAPACITY);
+    }
+}
+
+// counts[(first output index of tile t) - 1] += lead[t]
+__global__ void rle_fixup_kernel(const u32* __restrict__ lead, const u64* __restrict__ status, u32 tiles, u32* counts,
+                                 u64 cap, u32* err) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 || t >= tiles) return;
+    const u32 l = lead[t];
+    if (l == 0) return;
+    const u64 excl = status[t - 1] & ZK_ST_VALUE_MASK;   // inclusive prefix of the tile before
+    if (excl == 0 || excl - 1 >= cap) return;
+    const u32 old = atomicAdd(&counts[excl - 1], l);
+    if (old + l < old) atomicOr(err, ZK_DERR_COUNT_OVERFLOW);
+}
+
+int rle(zk_ctx* c, const u64* sorted, uint64_t n, u64* uniq, u32* counts, uint64_t cap, uint64_t* n_unique) {
+    *n_unique = 0;
+    if (n == 0) return ZK_OK;
+    SelState st;
+    st.tiles = (u32)div_up(n, SEL_TILE);
+    u32* lead;
+    ZK_TRY(arena_alloc(c, sizeof(u32) * st.tiles, (void**)&lead));
+    ZK_TRY(lookback_begin(c, st.tiles, st.tiles, &st.epoch, &st.ticket_base));
+    st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9;
+    hipLaunchKernelGGL(rle_kernel, dim3(st.tiles), dim3(SEL_BLOCK), 0, c->stream, sorted, (u64)n, uniq, counts, (u64)cap, lead, st);
+    ZK_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(rle_fixup_kernel, dim3((u32)div_up(st.tiles, 256)), dim3(256), 0, c->stream, lead, c->status, st.tiles,
+                       counts, (u64)cap, c->d_err);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, c->d_scalars + 9, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    *n_unique = c->h_scalars[9];
+    ZK_TRY(check_device_error(c));
+    return ZK_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// generic flag -> compact kernels
+// ---------------------------------------------------------------------------------------
+struct TrimOp {          // K10
+    const u64* keys; const void* cnts; int cbits; u64 lo, hi; u64* ok; void* oc;
+    struct R { u64 k; u64 c; };
+    __device__ bool load(u64 idx, R& r) const {
+        r.k = keys[idx];
+        r.c = (cbits == 32) ? (u64)((const u32*)cnts)[idx] : ((const u64*)cnts)[idx];
+        return r.c >= lo && (hi == 0 || r.c <= hi);
+    }
+    __device__ void store(u64 pos, const R& r) const {
+        ok[pos] = r.k;
+        if (cbits == 32) ((u32*)oc)[pos] = (u32)r.c; else ((u64*)oc)[pos] = r.c;
+    }
+};
+struct DedupeOp {        // K8
+    const u64* keys; int shift; u64* out;
+    struct R { u64 y; };
+    __device__ bool load(u64 idx, R& r) const {
+        r.y = keys[idx] >> shift;
+        return idx == 0 || (keys[idx - 1] >> shift) != r.y;
+    }
+    __device__ void store(u64 pos, const R& r) const { out[pos] = r.y; }
+};
+struct SubsampleOp {     // K2: float(murmer(x, seed)) / float(2**61 - 1) < p, in doubles as the reference
+    const u64* keys; u64 seed; double p; u64* out;
+    struct R { u64 k; };
+    __device__ bool load(u64 idx, R& r) const {
+        r.k = keys[idx];
+        const double u = (double)murmer(r.k, seed) / (double)0x1FFFFFFFFFFFFFFFull;
+        return u < p;
+    }
+    __device__ void store(u64 pos, const R& r) const { out[pos] = r.k; }
+};
+
+struct SubPairOp {       // K2 applied to an already counted set, in place (loads precede any store
+                         // that could alias them: a tile learns its offset only after every
+                         // earlier tile has loaded its inputs)
+    u64* keys; u32* cnts; u64 seed; double p;
+    struct R { u64 k; u32 c; };
+    __device__ bool load(u64 idx, R& r) const {
+        r.k = keys[idx]; r.c = cnts[idx];
+        const double u = (double)murmer(r.k, seed) / (double)0x1FFFFFFFFFFFFFFFull;
+        return u < p;
+    }
+    __device__ void store(u64 pos, const R& r) const { keys[pos] = r.k; cnts[pos] = r.c; }
+};
+
+template <class Op>
+__global__ __launch_bounds__(SEL_BLOCK) void select_kernel(Op op, u64 n, u64 cap, SelState st) {
+    __shared__ SelSmem sm;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 tile = take_ticket(st.ticket, &sm.ticket) - st.ticket_base;
+    const u64 base = (u64)tile * SEL_TILE + (u64)wave * (64 * SEL_ITEMS);
+    typename Op::R r[SEL_ITEMS];
+    u64 km[SEL_ITEMS];
+    u32 wave_total = 0;
+#pragma unroll
+    for (int i = 0; i < SEL_ITEMS; i++) {
+        const u64 idx = base + (u64)i * 64 + lane;
+        const bool keep = (idx < n) && op.load(idx, r[i]);
+        km[i] = __ballot(keep);
+        wave_total += (u32)__popcll(km[i]);
+    }
+    u32 tile_total;
+    u64 pos = select_wave_base(sm, st, tile, wave_total, &tile_total);
+#pragma unroll
+    for (int i = 0; i < SEL_ITEMS; i++) {
+        if ((km[i] >> lane) & 1ull) {
+            const u64 q = pos + popc_below(km[i]);
+            if (q < cap) op.store(q, r[i]);
+        }
+        pos += (u32)__popcll(km[i]);
+    }
+    if (threadIdx.x == 0 && tile == st.tiles - 1 && sm.tile_excl + tile_total > cap) atomicOr(st.err, ZK_DERR_CAPACITY);
+}
+
+template <class Op>
+static int run_select(zk_ctx* c, const Op& op, uint64_t n, uint64_t cap, uint64_t* n_out) {
+    *n_out = 0;
+    if (n == 0) return ZK_OK;
+    SelState st;
+    st.tiles = (u32)div_up(n, SEL_TILE);
+    ZK_TRY(lookback_begin(c, st.tiles, st.tiles, &st.epoch, &st.ticket_base));
+    st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9;
+    hipLaunchKernelGGL((select_kernel<Op>), dim3(st.tiles), dim3(SEL_BLOCK), 0, c->stream, op, (u64)n, (u64)cap, st);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, c->d_scalars + 9, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    *n_out = c->h_scalars[9];
+    return check_device_error(c);
+}
+
+int trim(zk_ctx* c, const u64* keys, const void* cnts, int cbits, uint64_t n, u64 lo, u64 hi, u64* ok, void* oc,
+         uint64_t cap, uint64_t* n_out) {
+    TrimOp op{keys, cnts, cbits, lo, hi, ok, oc};
+    return run_select(c, op, n, cap, n_out);
+}
+int project_dedupe(zk_ctx* c, const u64* keys, uint64_t n, int shift, u64* out, uint64_t cap, uint64_t* n_out) {
+    DedupeOp op{keys, shift, out};
+    return run_select(c, op, n, cap, n_out);
+}
+int subsample_pairs(zk_ctx* c, u64* keys, u32* cnts, uint64_t n, u64 seed, double p, uint64_t* n_out) {
+    SubPairOp op{keys, cnts, seed, p};
+    return run_select(c, op, n, n, n_out);
+}
+int subsample(zk_ctx* c, const u64* keys, uint64_t n, u64 seed, double p, u64* out, uint64_t cap, uint64_t* n_out) {
+    SubsampleOp op{keys, seed, p, out};
+    return run_select(c, op, n, cap, n_out);
+}
+
+// ---------------------------------------------------------------------------------------
+// K1 as a list: k-mers of a base stream in the reference's order (x then rc(x) per window)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SEL_BLOCK) void encode_list_kernel(const u8* __restrict__ stream, u64 n_bytes, int K, int both,
+                                                                u64* __restrict__ out, u64 cap, u64* acgt, SelState st) {
+    __shared__ SelSmem sm;
+    __shared__ TileImage<SEL_TILE> img;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 tile = take_ticket(st.ticket, &sm.ticket) - st.ticket_base;
+    stage_tile<SEL_BLOCK, SEL_TILE>(stream, n_bytes, (u64)tile * SEL_TILE, img);
+    u64 x[SEL_ITEMS];
+    u64 km[SEL_ITEMS];
+    u32 wave_total = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for (int i = 0; i < SEL_ITEMS; i++) {
+        const int p = wave * (64 * SEL_ITEMS) + i * 64 + lane;
+        const bool ok = window_at(img, p, K, x[i]);
+        km[i] = __ballot(ok);
+        wave_total += (u32)__popcll(km[i]);
+        if (ok) {
+            const u32 f = (u32)(x[i] & 3), b = (u32)(revcomp(K, x[i]) & 3);
+            a0 += (f == 0) + (both && b == 0); a1 += (f == 1) + (both && b == 1);
+            a2 += (f == 2) + (both && b == 2); a3 += (f == 3) + (both && b == 3);
+        }
+    }
+    u32 tile_total;
+    u64 pos = select_wave_base(sm, st, tile, wave_total, &tile_total);
+    const u64 mul = both ? 2 : 1;
+#pragma unroll
+    for (int i = 0; i < SEL_ITEMS; i++) {
+        if ((km[i] >> lane) & 1ull) {
+            const u64 q = (pos + popc_below(km[i])) * mul;
+            if (q + mul <= cap) {
+                out[q] = x[i];
+                if (both) out[q + 1] = revcomp(K, x[i]);
+            }
+        }
+        pos += (u32)__popcll(km[i]);
+    }
+    if (acgt) {
+        a0 = wave_sum_u32(a0); a1 = wave_sum_u32(a1); a2 = wave_sum_u32(a2); a3 = wave_sum_u32(a3);
+        if (lane == 0) {
+            if (a0) atomicAdd(&acgt[0], (u64)a0);
+            if (a1) atomicAdd(&acgt[1], (u64)a1);
+            if (a2) atomicAdd(&acgt[2], (u64)a2);
+            if (a3) atomicAdd(&acgt[3], (u64)a3);
+        }
+    }
+    if (threadIdx.x == 0 && tile == st.tiles - 1 && (sm.tile_excl + tile_total) * mul > cap) atomicOr(st.err, ZK_DERR_CAPACITY);
+}
+
+int encode_list(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int both, u64* out, uint64_t cap, uint64_t* n_out,
+                uint64_t acgt[4]) {
+    *n_out = 0;
+    if (acgt) acgt[0] = acgt[1] = acgt[2] = acgt[3] = 0;
+    if (n_bytes == 0) return ZK_OK;
+    if ((uintptr_t)stream & 15) return fail(c, ZK_EINVAL, "base stream must be 16-byte aligned");
+    SelState st;
+    st.tiles = (u32)div_up(n_bytes, SEL_TILE);
+    ZK_TRY(lookback_begin(c, st.tiles, st.tiles, &st.epoch, &st.ticket_base));
+    st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9;
+    u64* d_acgt = c->d_scalars + 0;
+    ZK_HIP(c, hipMemsetAsync(d_acgt, 0, 4 * sizeof(u64), c->stream));
+    hipLaunchKernelGGL(encode_list_kernel, dim3(st.tiles), dim3(SEL_BLOCK), 0, c->stream, stream, (u64)n_bytes, K, both, out,
+                       (u64)cap, d_acgt, st);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(u64) * 16, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    *n_out = c->h_scalars[9] * (both ? 2 : 1);
+    if (acgt) for (int b = 0; b < 4; b++) acgt[b] = c->h_scalars[b];
+    return check_device_error(c);
+}
+
+// ---------------------------------------------------------------------------------------
+// K7: histogram of counts.  Values below HIST_DENSE go to LDS bins; the (rare) larger ones are
+// appended to a list that the host folds in.
+// ---------------------------------------------------------------------------------------
+constexpr int HIST_DENSE = 4096;
+
+template <typename CT>
+__global__ __launch_bounds__(256) void count_hist_kernel(const CT* __restrict__ counts, u64 n, u64* __restrict__ dense,
+                                                         u64* __restrict__ big, u64 big_cap, u64* big_n) {
+    __shared__ u32 bins[HIST_DENSE];
+    for (int i = threadIdx.x; i < HIST_DENSE; i += 256) bins[i] = 0;
+    __syncthreads();
+    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
+        const u64 v = counts[i];
+        if (v < HIST_DENSE) atomicAdd(&bins[v], 1u);
+        else {
+            const u64 slot = atomicAdd(big_n, 1ull);
+            if (slot < big_cap) big[slot] = v;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HIST_DENSE; i += 256)
+        if (bins[i]) atomicAdd(&dense[i], (u64)bins[i]);
+}
+
+int count_hist(zk_ctx* c, const void* counts, int count_bits, uint64_t n, uint64_t* vals, uint64_t* freq,
+               uint64_t cap_bins, uint64_t* n_bins) {
+    *n_bins = 0;
+    if (n == 0) return ZK_OK;
+    const uint64_t big_cap = n < (1ull << 22) ? n : (1ull << 22);
+    u64 *dense, *big;
+    ZK_TRY(arena_alloc(c, sizeof(u64) * HIST_DENSE, (void**)&dense));
+    ZK_TRY(arena_alloc(c, sizeof(u64) * big_cap, (void**)&big));
+    u64* big_n = c->d_scalars + 10;
+    ZK_HIP(c, hipMemsetAsync(dense, 0, sizeof(u64) * HIST_DENSE, c->stream));
+    ZK_HIP(c, hipMemsetAsync(big_n, 0, sizeof(u64), c->stream));
+    u32 grid = (u32)(div_up(n, 256 * 16) < (uint64_t)c->num_cus * 8 ? div_up(n, 256 * 16) : (uint64_t)c->num_cus * 8);
+    if (count_bits == 32)
+        hipLaunchKernelGGL((count_hist_kernel<u32>), dim3(grid), dim3(256), 0, c->stream, (const u32*)counts, (u64)n, dense, big, (u64)big_cap, big_n);
+    else
+        hipLaunchKernelGGL((count_hist_kernel<u64>), dim3(grid), dim3(256), 0, c->stream, (const u64*)counts, (u64)n, dense, big, (u64)big_cap, big_n);
+    ZK_HIP(c, hipGetLastError());
+    std::vector<u64> hd(HIST_DENSE);
+    u64* h_dense = hd.data();
+    ZK_HIP(c, hipMemcpyAsync(h_dense, dense, sizeof(u64) * HIST_DENSE, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 10, big_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    const uint64_t nb = c->h_scalars[10];
+    if (nb > big_cap) return fail(c, ZK_ENOSPC, "count histogram: %llu counts >= %d exceed the side list", (unsigned long long)nb, HIST_DENSE);
+    uint64_t m = 0;
+    for (int v = 0; v < HIST_DENSE; v++)
+        if (h_dense[v]) {
+            if (m >= cap_bins) return fail(c, ZK_ENOSPC, "histogram has more than %llu bins", (unsigned long long)cap_bins);
+            vals[m] = v; freq[m] = h_dense[v]; m++;
+        }
+    if (nb) {
+        std::vector<u64> hb(nb);
+        u64* h_big = hb.data();
+        ZK_HIP(c, hipMemcpy(h_big, big, sizeof(u64) * nb, hipMemcpyDeviceToHost));
+        std::sort(hb.begin(), hb.end());   // the few counts >= HIST_DENSE
+        for (uint64_t i = 0; i < nb;) {
+            uint64_t j = i;
+            while (j < nb && h_big[j] == h_big[i]) j++;
+            if (m >= cap_bins) return fail(c, ZK_ENOSPC, "histogram has more than %llu bins", (unsigned long long)cap_bins);
+            vals[m] = h_big[i]; freq[m] = j - i; m++;
+            i = j;
+        }
+    }
+    *n_bins = m;
+    return ZK_OK;
+}
+
+}  // namespace zk

@@ -1,0 +1,278 @@
+// setops.hip -- sorted-set algebra on (k-mer, count) arrays with merge-path partitioning:
+//   K5  2-way union with summed counts   (merge.merge, zotmer/commands/merge.py:26-86; and the
+//                                         merge half of kmerize.merge, commands/kmerize.py:41-132)
+//   K6  k-way union-sum                  (mergeNinto, commands/merge.py:127-163, kmerize.py:269-304)
+//                                         as a tree of K5 passes
+//   K9  intersect count (a, b, c)        (dist.split, zotmer/library/dist.py:241-265)
+//
+// A partition kernel cuts the merged sequence of A and B into tiles of TILE outputs by binary
+// search on the merge-path diagonals (ties: A before B).  A workgroup stages its A slice and B
+// slice in LDS (one element of halo on each side), every thread finds its own diagonal in LDS
+// and merges ITEMS elements serially.  With A first on ties an equal pair is always adjacent:
+// the A element absorbs the B count and the B element is dropped, so the union-sum is fused
+// into the merge; survivors are compacted through LDS and written as one contiguous run whose
+// position comes from a decoupled look-back over the tiles.
+//
+// Algorithmic bytes: (8 + cb) per input element read, (8 + cb) per output element written
+// (cb = 4 or 8 count bytes); K9 reads 8 per element and writes 24 bytes in total.
+#include "internal.hpp"
+
+namespace zk {
+
+constexpr int MRG_BLOCK = 256;
+constexpr int MRG_ITEMS = 8;
+constexpr int MRG_TILE = MRG_BLOCK * MRG_ITEMS;
+constexpr int MRG_NW = MRG_BLOCK / 64;
+
+// part[t] = number of A elements among the first min(t*TILE, nA+nB) merged elements
+__global__ void merge_partition_kernel(const u64* __restrict__ A, u64 nA, const u64* __restrict__ B, u64 nB, u64* __restrict__ part,
+                                       u32 tiles) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > tiles) return;
+    u64 D = (u64)t * MRG_TILE;
+    if (D > nA + nB) D = nA + nB;
+    u64 lo = D > nB ? D - nB : 0, hi = D < nA ? D : nA;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (A[mid] <= B[D - mid - 1]) lo = mid + 1; else hi = mid;
+    }
+    part[t] = lo;
+}
+
+template <typename CT>
+struct MergeSmem {
+    union {
+        struct {
+            u64 ka[MRG_TILE + 2];   // [0] = left halo A[a0-1]
+            u64 kb[MRG_TILE + 2];   // [nBt] = right halo B[b1]
+            CT ca[MRG_TILE + 2];
+            CT cb[MRG_TILE + 2];
+        } in;
+        struct {
+            u64 k[MRG_TILE];
+            CT c[MRG_TILE];
+        } out;
+    };
+    u32 wtot[MRG_NW];
+    u64 tile_excl;
+    u32 ticket;
+};
+
+struct MergeState {
+    u64* status; u32* ticket; u32 ticket_base; u32 epoch; u32* err; u64* d_total; u32 tiles;
+};
+
+template <typename CT>
+__global__ __launch_bounds__(MRG_BLOCK) void union_sum_kernel(const u64* __restrict__ A, const CT* __restrict__ cA, u64 nA,
+                                                              const u64* __restrict__ B, const CT* __restrict__ cB, u64 nB,
+                                                              const u64* __restrict__ part, u64* __restrict__ ok,
+                                                              CT* __restrict__ oc, u64 cap, u64* acgt_w, MergeState st) {
+    __shared__ MergeSmem<CT> sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 tile = take_ticket(st.ticket, &sm.ticket) - st.ticket_base;
+    const u64 a0 = part[tile], a1 = part[tile + 1];
+    u64 d0 = (u64)tile * MRG_TILE, d1 = d0 + MRG_TILE;
+    if (d1 > nA + nB) d1 = nA + nB;
+    const u64 b0 = d0 - a0, b1 = d1 - a1;
+    const int nAt = (int)(a1 - a0), nBt = (int)(b1 - b0);
+
+    // stage: ka[1 + i] = A[a0 + i], ka[0] = A[a0 - 1]; kb[j] = B[b0 + j], kb[nBt] = B[b1]
+    for (int i = tid; i < nAt + 1; i += MRG_BLOCK) {
+        const u64 g = a0 + i;           // element index + 1
+        sm.in.ka[i] = (g >= 1) ? A[g - 1] : 0ull;
+        sm.in.ca[i] = (g >= 1) ? cA[g - 1] : (CT)0;
+    }
+    for (int j = tid; j < nBt + 1; j += MRG_BLOCK) {
+        const u64 g = b0 + j;
+        sm.in.kb[j] = (g < nB) ? B[g] : 0ull;
+        sm.in.cb[j] = (g < nB) ? cB[g] : (CT)0;
+    }
+    __syncthreads();
+    const bool have_left = a0 > 0;
+    const bool have_right = b1 < nB;
+
+    // this thread's diagonal inside the tile
+    const int total = nAt + nBt;
+    int d = tid * MRG_ITEMS;
+    if (d > total) d = total;
+    int lo = d > nBt ? d - nBt : 0, hi = d < nAt ? d : nAt;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sm.in.ka[1 + mid] <= sm.in.kb[d - mid - 1]) lo = mid + 1; else hi = mid;
+    }
+    int i = lo, j = d - lo;
+    u64 rk[MRG_ITEMS];
+    CT rc[MRG_ITEMS];
+    u32 keep = 0;
+#pragma unroll
+    for (int s = 0; s < MRG_ITEMS; s++) {
+        rk[s] = 0; rc[s] = 0;
+        if (d + s < total) {
+            const bool hasA = i < nAt, hasB = j < nBt;
+            const u64 ak = sm.in.ka[1 + i], bk = sm.in.kb[j];
+            if (hasA && (!hasB || ak <= bk)) {
+                // the equal partner, if any, is the B cursor (possibly the right halo)
+                const bool bvalid = (j < nBt) || have_right;
+                CT c = sm.in.ca[1 + i];
+                if (bvalid && bk == ak) {
+                    const CT c2 = c + sm.in.cb[j];
+                    if (c2 < c) atomicOr(st.err, ZK_DERR_COUNT_OVERFLOW);
+                    c = c2;
+                }
+                rk[s] = ak; rc[s] = c; keep |= 1u << s;
+                i++;
+            } else {
+                // dropped when the A element just before it (possibly the left halo) is equal
+                const bool avalid = (i > 0) || have_left;
+                const bool dup = avalid && sm.in.ka[i] == bk;
+                rk[s] = bk; rc[s] = sm.in.cb[j];
+                if (!dup) keep |= 1u << s;
+                j++;
+            }
+        }
+    }
+    // compact: blocked arrangement -> exclusive scan of per-thread totals
+    const u32 mine = (u32)__popc(keep);
+    const u32 inc = wave_incl_scan_u32(mine);
+    if (lane == 63) sm.wtot[wave] = inc;
+    __syncthreads();           // also: everyone is done reading sm.in
+    u32 wex = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < MRG_NW; w++) { if (w < wave) wex += sm.wtot[w]; tot += sm.wtot[w]; }
+    if (wave == 0) {
+        const u64 ex = lookback_exclusive(st.status, tile, tot, st.epoch, st.err);
+        if (lane == 0) {
+            sm.tile_excl = ex;
+            if (tile == st.tiles - 1) *st.d_total = ex + tot;
+        }
+    }
+    u32 q = wex + inc - mine;
+    u64 w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+#pragma unroll
+    for (int s = 0; s < MRG_ITEMS; s++) {
+        if ((keep >> s) & 1u) {
+            sm.out.k[q] = rk[s]; sm.out.c[q] = rc[s]; q++;
+            const u32 b = (u32)(rk[s] & 3);
+            const u64 c = (u64)rc[s];
+            w0 += (b == 0) ? c : 0; w1 += (b == 1) ? c : 0; w2 += (b == 2) ? c : 0; w3 += (b == 3) ? c : 0;
+        }
+    }
+    __syncthreads();
+    const u64 base = sm.tile_excl;
+    for (u32 s = tid; s < tot; s += MRG_BLOCK) {
+        if (base + s < cap) { ok[base + s] = sm.out.k[s]; oc[base + s] = sm.out.c[s]; }
+    }
+    if (acgt_w) {
+        w0 = wave_sum_u64(w0); w1 = wave_sum_u64(w1); w2 = wave_sum_u64(w2); w3 = wave_sum_u64(w3);
+        if (lane == 0) {
+            if (w0) atomicAdd(&acgt_w[0], w0);
+            if (w1) atomicAdd(&acgt_w[1], w1);
+            if (w2) atomicAdd(&acgt_w[2], w2);
+            if (w3) atomicAdd(&acgt_w[3], w3);
+        }
+    }
+    if (tid == 0 && tile == st.tiles - 1 && base + tot > cap) atomicOr(st.err, ZK_DERR_CAPACITY);
+}
+
+// K9: number of common elements of two sorted unique arrays
+__global__ __launch_bounds__(MRG_BLOCK) void intersect_kernel(const u64* __restrict__ A, u64 nA, const u64* __restrict__ B, u64 nB,
+                                                              const u64* __restrict__ part, u64* __restrict__ n_common) {
+    __shared__ u64 ka[MRG_TILE + 2];
+    __shared__ u64 kb[MRG_TILE + 2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const u32 tile = blockIdx.x;
+    const u64 a0 = part[tile], a1 = part[tile + 1];
+    u64 d0 = (u64)tile * MRG_TILE, d1 = d0 + MRG_TILE;
+    if (d1 > nA + nB) d1 = nA + nB;
+    const u64 b0 = d0 - a0, b1 = d1 - a1;
+    const int nAt = (int)(a1 - a0), nBt = (int)(b1 - b0);
+    for (int i = tid; i < nAt + 1; i += MRG_BLOCK) { const u64 g = a0 + i; ka[i] = (g >= 1) ? A[g - 1] : 0ull; }
+    for (int j = tid; j < nBt; j += MRG_BLOCK) kb[j] = B[b0 + j];
+    __syncthreads();
+    const bool have_left = a0 > 0;
+    const int total = nAt + nBt;
+    int d = tid * MRG_ITEMS;
+    if (d > total) d = total;
+    int lo = d > nBt ? d - nBt : 0, hi = d < nAt ? d : nAt;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (ka[1 + mid] <= kb[d - mid - 1]) lo = mid + 1; else hi = mid;
+    }
+    int i = lo, j = d - lo;
+    u32 hits = 0;
+#pragma unroll
+    for (int s = 0; s < MRG_ITEMS; s++) {
+        if (d + s < total) {
+            const bool hasA = i < nAt, hasB = j < nBt;
+            if (hasA && (!hasB || ka[1 + i] <= kb[j])) i++;
+            else {
+                const bool avalid = (i > 0) || have_left;
+                hits += (avalid && ka[i] == kb[j]) ? 1u : 0u;
+                j++;
+            }
+        }
+    }
+    hits = wave_sum_u32(hits);
+    if (lane == 0 && hits) atomicAdd(n_common, (u64)hits);
+}
+
+static int make_partition(zk_ctx* c, const u64* A, u64 nA, const u64* B, u64 nB, u64** part, u32* tiles) {
+    *tiles = (u32)div_up(nA + nB, MRG_TILE);
+    ZK_TRY(arena_alloc(c, sizeof(u64) * ((uint64_t)*tiles + 1), (void**)part));
+    hipLaunchKernelGGL(merge_partition_kernel, dim3((u32)div_up((uint64_t)*tiles + 1, 256)), dim3(256), 0, c->stream, A, nA, B, nB,
+                       *part, *tiles);
+    ZK_HIP(c, hipGetLastError());
+    return ZK_OK;
+}
+
+template <typename CT>
+static int union_sum_t(zk_ctx* c, const u64* A, const CT* cA, u64 nA, const u64* B, const CT* cB, u64 nB, u64* ok, CT* oc,
+                       uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]) {
+    *n_out = 0;
+    if (acgt_w) acgt_w[0] = acgt_w[1] = acgt_w[2] = acgt_w[3] = 0;
+    if (nA + nB == 0) return ZK_OK;
+    u64* part; u32 tiles;
+    ZK_TRY(make_partition(c, A, nA, B, nB, &part, &tiles));
+    MergeState st;
+    st.tiles = tiles;
+    ZK_TRY(lookback_begin(c, tiles, tiles, &st.epoch, &st.ticket_base));
+    st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9;
+    u64* d_acgt = nullptr;
+    if (acgt_w) {
+        d_acgt = c->d_scalars + 0;
+        ZK_HIP(c, hipMemsetAsync(d_acgt, 0, 4 * sizeof(u64), c->stream));
+    }
+    hipLaunchKernelGGL((union_sum_kernel<CT>), dim3(tiles), dim3(MRG_BLOCK), 0, c->stream, A, cA, nA, B, cB, nB, part, ok, oc,
+                       (u64)cap, d_acgt, st);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(u64) * 16, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    *n_out = c->h_scalars[9];
+    if (acgt_w) for (int b = 0; b < 4; b++) acgt_w[b] = c->h_scalars[b];
+    return check_device_error(c);
+}
+
+int union_sum(zk_ctx* c, const u64* A, const void* cA, u64 nA, const u64* B, const void* cB, u64 nB, u64* ok, void* oc,
+              int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]) {
+    if (count_bits == 32)
+        return union_sum_t<u32>(c, A, (const u32*)cA, nA, B, (const u32*)cB, nB, ok, (u32*)oc, cap, n_out, acgt_w);
+    return union_sum_t<u64>(c, A, (const u64*)cA, nA, B, (const u64*)cB, nB, ok, (u64*)oc, cap, n_out, acgt_w);
+}
+
+int intersect_count(zk_ctx* c, const u64* A, u64 nA, const u64* B, u64 nB, uint64_t abc[3]) {
+    abc[0] = 0; abc[1] = nA; abc[2] = nB;
+    if (nA == 0 || nB == 0) return ZK_OK;
+    u64* part; u32 tiles;
+    ZK_TRY(make_partition(c, A, nA, B, nB, &part, &tiles));
+    u64* d_n = c->d_scalars + 11;
+    ZK_HIP(c, hipMemsetAsync(d_n, 0, sizeof(u64), c->stream));
+    hipLaunchKernelGGL(intersect_kernel, dim3(tiles), dim3(MRG_BLOCK), 0, c->stream, A, nA, B, nB, part, d_n);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 11, d_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    const uint64_t a = c->h_scalars[11];
+    abc[0] = a; abc[1] = nA - a; abc[2] = nB - a;
+    return ZK_OK;
+}
+
+}  // namespace zk

@@ -1,0 +1,319 @@
+"""
+ctypes binding of libzotk.so (include/zotk.h) -- the only way Python reaches the HIP kernels.
+
+There is no CPU fallback: if the shared library is missing, or no MI355X is visible, the calls
+below raise.  The library is built in-tree by `__graft_entry__.build()` (or
+`make -C zotmer_amd/csrc`) so that it travels with the source tree.
+
+Device memory is handled through small `DeviceArray` objects (pointer + dtype + length) that
+free themselves; numpy arrays go up with `Context.upload` and come back with
+`DeviceArray.to_host`.  torch tensors can be used instead: pass `tensor.data_ptr()` wrapped in
+`DeviceArray.borrow(...)`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzotk.so")
+
+ZK_OK, ZK_EINVAL, ZK_ENOMEM, ZK_EHIP, ZK_ENOSPC, ZK_EOVERFLOW, ZK_EINTERNAL, ZK_ERANGE = 0, -1, -2, -3, -4, -5, -6, -7
+KMERIZE_CANONICAL, KMERIZE_BOTH, KMERIZE_SUBSAMPLE = 0, 1, 2
+
+_ERRNAMES = {-1: "ZK_EINVAL", -2: "ZK_ENOMEM", -3: "ZK_EHIP", -4: "ZK_ENOSPC", -5: "ZK_EOVERFLOW",
+             -6: "ZK_EINTERNAL", -7: "ZK_ERANGE"}
+
+
+class ZotkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (_ERRNAMES.get(code, code), msg))
+        self.code = code
+
+
+class KmerizeStats(C.Structure):
+    _fields_ = [("n_windows", C.c_uint64), ("n_instances", C.c_uint64), ("n_unique", C.c_uint64),
+                ("n_canonical", C.c_uint64), ("acgt", C.c_uint64 * 4)]
+
+
+# name -> (restype, argtypes): every symbol include/zotk.h declares
+_vp, _u64, _u32, _i, _d = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_double
+_pu64 = C.POINTER(C.c_uint64)
+SIGNATURES = {
+    "zk_create": (_vp, [_i, _u64]),
+    "zk_destroy": (None, [_vp]),
+    "zk_last_error": (C.c_char_p, [_vp]),
+    "zk_set_stream": (_i, [_vp, _vp]),
+    "zk_get_stream": (_vp, [_vp]),
+    "zk_sync": (_i, [_vp]),
+    "zk_reserve": (_i, [_vp, _u64]),
+    "zk_mem_info": (_i, [_vp, _pu64, _pu64]),
+    "zk_alloc": (_i, [_vp, _u64, C.POINTER(_vp)]),
+    "zk_free": (_i, [_vp, _vp]),
+    "zk_upload": (_i, [_vp, _vp, _vp, _u64]),
+    "zk_download": (_i, [_vp, _vp, _vp, _u64]),
+    "zk_copy": (_i, [_vp, _vp, _vp, _u64]),
+    "zk_pack_reads": (_i, [_vp, _vp, _vp, _u64, _vp]),
+    "zk_encode": (_i, [_vp, _vp, _u64, _i, _i, _vp, _u64, _pu64, _pu64]),
+    "zk_subsample": (_i, [_vp, _vp, _u64, _u64, _d, _vp, _u64, _pu64]),
+    "zk_sort_keys": (_i, [_vp, _vp, _u64, _i]),
+    "zk_sort_pairs": (_i, [_vp, _vp, _vp, _u64, _i]),
+    "zk_rle": (_i, [_vp, _vp, _u64, _vp, _vp, _u64, _pu64]),
+    "zk_sort_count": (_i, [_vp, _vp, _u64, _i, _vp, _vp, _u64, _pu64]),
+    "zk_kmerize": (_i, [_vp, _vp, _u64, _i, _i, _d, _u64, _vp, _vp, _u64, C.POINTER(KmerizeStats)]),
+    "zk_hist": (_i, [_vp, _vp, _i, _u64, _pu64, _pu64, _u64, _pu64]),
+    "zk_widen_counts": (_i, [_vp, _vp, _vp, _u64]),
+    "zk_union_sum": (_i, [_vp, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _i, _u64, _pu64, _pu64]),
+    "zk_merge_n": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _pu64, _vp, _vp, _u64, _pu64, _pu64]),
+    "zk_project_dedupe": (_i, [_vp, _vp, _u64, _i, _vp, _u64, _pu64]),
+    "zk_split": (_i, [_vp, _vp, _u64, _vp, _u64, _pu64]),
+    "zk_trim": (_i, [_vp, _vp, _vp, _i, _u64, _u64, _u64, _vp, _vp, _u64, _pu64]),
+    "zk_synth_reads": (_i, [_vp, _u64, _u64, _u64, _i, _u64, _u32, _u32, _vp]),
+    "zk_checksum": (_i, [_vp, _vp, _vp, _u64, _pu64]),
+    "zk_stream_checksum": (_i, [_vp, _vp, _u64, _i, _pu64]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libzotk.so and bind every declared symbol.  Raises if the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ZotkError(ZK_EINTERNAL, "%s is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                          "or `make -C zotmer_amd/csrc` (needs hipcc; there is no CPU fallback)" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError here = header and library disagree
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class DeviceArray:
+    """A typed view of device memory: .ptr, .dtype, .n (elements).  Owns the allocation unless borrowed."""
+
+    def __init__(self, ctx, ptr, dtype, n, owned=True, keep=None):
+        self.ctx, self.ptr, self.dtype, self.n, self.owned, self._keep = ctx, ptr, np.dtype(dtype), int(n), owned, keep
+
+    @classmethod
+    def borrow(cls, ctx, ptr, dtype, n, keep=None):
+        return cls(ctx, ptr, dtype, n, owned=False, keep=keep)
+
+    @property
+    def nbytes(self):
+        return self.n * self.dtype.itemsize
+
+    def view(self, n, offset=0):
+        """First n elements (from element `offset`) as a borrowed array that keeps this one alive."""
+        return DeviceArray(self.ctx, self.ptr + offset * self.dtype.itemsize, self.dtype, n, owned=False, keep=self)
+
+    def to_host(self, n=None):
+        n = self.n if n is None else int(n)
+        out = np.empty(n, dtype=self.dtype)
+        if n:
+            self.ctx._check(load().zk_download(self.ctx.h, out.ctypes.data, self.ptr, n * self.dtype.itemsize))
+        return out
+
+    def free(self):
+        if self.owned and self.ptr and self.ctx.h:
+            load().zk_free(self.ctx.h, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One zk_ctx: one GPU, one stream."""
+
+    def __init__(self, device=0, workspace_bytes=0):
+        self.lib = load()
+        self.h = self.lib.zk_create(device, workspace_bytes)
+        if not self.h:
+            raise ZotkError(ZK_EHIP, "zk_create(%d) failed: no MI355X visible to HIP (there is no CPU fallback)" % device)
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.lib.zk_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != ZK_OK:
+            raise ZotkError(rc, self.lib.zk_last_error(self.h).decode(errors="replace"))
+
+    # ---- memory ---------------------------------------------------------------------------
+    def mem_info(self):
+        f, t = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.zk_mem_info(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
+    def reserve(self, nbytes):
+        self._check(self.lib.zk_reserve(self.h, int(nbytes)))
+
+    def sync(self):
+        self._check(self.lib.zk_sync(self.h))
+
+    def empty(self, n, dtype):
+        dt = np.dtype(dtype)
+        p = C.c_void_p(0)
+        self._check(self.lib.zk_alloc(self.h, max(int(n), 1) * dt.itemsize, C.byref(p)))
+        return DeviceArray(self, p.value, dt, n)
+
+    def upload(self, arr, dtype=None):
+        a = np.ascontiguousarray(arr, dtype=dtype)
+        d = self.empty(a.size, a.dtype)
+        if a.size:
+            self._check(self.lib.zk_upload(self.h, d.ptr, a.ctypes.data, a.nbytes))
+        return d
+
+    def upload_stream(self, data):
+        """bytes / uint8 array -> device base stream (zk_alloc memory is 256-byte aligned)."""
+        a = np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray, memoryview)) else np.asarray(data, np.uint8)
+        return self.upload(a)
+
+    # ---- kernels ------------------------------------------------------------------------------
+    def pack_reads(self, bases, offs):
+        n_reads = offs.n - 1
+        total = int(offs.to_host()[-1]) if offs.n else 0
+        out = self.empty(total + n_reads, np.uint8)
+        self._check(self.lib.zk_pack_reads(self.h, bases.ptr, offs.ptr, n_reads, out.ptr))
+        return out
+
+    def encode(self, stream, K, both=True):
+        cap = stream.n * (2 if both else 1)
+        out = self.empty(cap, np.uint64)
+        n = C.c_uint64(0)
+        acgt = (C.c_uint64 * 4)()
+        self._check(self.lib.zk_encode(self.h, stream.ptr, stream.n, K, int(both), out.ptr, cap, C.byref(n), acgt))
+        return out.view(n.value), [int(v) for v in acgt]
+
+    def subsample(self, kmers, seed, p):
+        out = self.empty(kmers.n, np.uint64)
+        n = C.c_uint64(0)
+        self._check(self.lib.zk_subsample(self.h, kmers.ptr, kmers.n, int(seed), float(p), out.ptr, kmers.n, C.byref(n)))
+        return out.view(n.value)
+
+    def sort_keys(self, keys, key_bits):
+        self._check(self.lib.zk_sort_keys(self.h, keys.ptr, keys.n, key_bits))
+        return keys
+
+    def sort_pairs(self, keys, vals, key_bits):
+        self._check(self.lib.zk_sort_pairs(self.h, keys.ptr, vals.ptr, keys.n, key_bits))
+        return keys, vals
+
+    def rle(self, sorted_keys, in_place=False):
+        uniq = sorted_keys if in_place else self.empty(sorted_keys.n, np.uint64)
+        cnt = self.empty(sorted_keys.n, np.uint32)
+        n = C.c_uint64(0)
+        self._check(self.lib.zk_rle(self.h, sorted_keys.ptr, sorted_keys.n, uniq.ptr, cnt.ptr, sorted_keys.n, C.byref(n)))
+        return uniq.view(n.value), cnt.view(n.value)
+
+    def sort_count(self, keys, key_bits):
+        uniq = self.empty(keys.n, np.uint64)
+        cnt = self.empty(keys.n, np.uint32)
+        n = C.c_uint64(0)
+        self._check(self.lib.zk_sort_count(self.h, keys.ptr, keys.n, key_bits, uniq.ptr, cnt.ptr, keys.n, C.byref(n)))
+        return uniq.view(n.value), cnt.view(n.value)
+
+    def kmerize(self, stream, K, flags=KMERIZE_CANONICAL, p=0.0, seed=0, cap=None, out=None):
+        """-> (kmers DeviceArray u64, counts DeviceArray u32, KmerizeStats).  `out` = (kmers, counts)
+        preallocated arrays to write into (their length is the capacity)."""
+        if out is None:
+            cap = int(cap) if cap is not None else 2 * stream.n
+            ok, oc = self.empty(cap, np.uint64), self.empty(cap, np.uint32)
+        else:
+            ok, oc = out
+            cap = min(ok.n, oc.n)
+        st = KmerizeStats()
+        self._check(self.lib.zk_kmerize(self.h, stream.ptr, stream.n, K, flags, float(p), int(seed), ok.ptr, oc.ptr, cap, C.byref(st)))
+        return ok.view(st.n_unique), oc.view(st.n_unique), st
+
+    def hist(self, counts):
+        bits = counts.dtype.itemsize * 8
+        cap = 1 << 16
+        while True:
+            vals = np.empty(cap, dtype=np.uint64)
+            freq = np.empty(cap, dtype=np.uint64)
+            n = C.c_uint64(0)
+            rc = self.lib.zk_hist(self.h, counts.ptr, bits, counts.n, vals.ctypes.data_as(_pu64), freq.ctypes.data_as(_pu64), cap, C.byref(n))
+            if rc == ZK_ENOSPC and cap < (1 << 26):
+                cap *= 8
+                continue
+            self._check(rc)
+            return {int(v): int(f) for v, f in zip(vals[:n.value], freq[:n.value])}
+
+    def widen(self, counts32):
+        out = self.empty(counts32.n, np.uint64)
+        self._check(self.lib.zk_widen_counts(self.h, counts32.ptr, out.ptr, counts32.n))
+        return out
+
+    def union_sum(self, xk, xc, yk, yc, want_acgt=False):
+        bits = xc.dtype.itemsize * 8
+        assert yc.dtype == xc.dtype
+        cap = xk.n + yk.n
+        ok, oc = self.empty(cap, np.uint64), self.empty(cap, xc.dtype)
+        n = C.c_uint64(0)
+        acgt = (C.c_uint64 * 4)()
+        self._check(self.lib.zk_union_sum(self.h, xk.ptr, xc.ptr, xk.n, yk.ptr, yc.ptr, yk.n, ok.ptr, oc.ptr, bits, cap,
+                                          C.byref(n), acgt if want_acgt else None))
+        r = (ok.view(n.value), oc.view(n.value))
+        return r + ([int(v) for v in acgt],) if want_acgt else r
+
+    def merge_n(self, sets):
+        """sets = [(kmers u64 DeviceArray, counts u64 DeviceArray), ...] -> (kmers, counts, acgt_weighted)."""
+        k = len(sets)
+        pk = (_vp * k)(*[s[0].ptr for s in sets])
+        pc = (_vp * k)(*[s[1].ptr for s in sets])
+        ns = (C.c_uint64 * k)(*[s[0].n for s in sets])
+        cap = sum(s[0].n for s in sets)
+        ok, oc = self.empty(cap, np.uint64), self.empty(cap, np.uint64)
+        n = C.c_uint64(0)
+        acgt = (C.c_uint64 * 4)()
+        self._check(self.lib.zk_merge_n(self.h, k, pk, pc, ns, ok.ptr, oc.ptr, cap, C.byref(n), acgt))
+        return ok.view(n.value), oc.view(n.value), [int(v) for v in acgt]
+
+    def project_dedupe(self, kmers, shift):
+        out = self.empty(kmers.n, np.uint64)
+        n = C.c_uint64(0)
+        self._check(self.lib.zk_project_dedupe(self.h, kmers.ptr, kmers.n, shift, out.ptr, kmers.n, C.byref(n)))
+        return out.view(n.value)
+
+    def split(self, x, y):
+        abc = (C.c_uint64 * 3)()
+        self._check(self.lib.zk_split(self.h, x.ptr, x.n, y.ptr, y.n, abc))
+        return tuple(int(v) for v in abc)
+
+    def trim(self, kmers, counts, lo, hi=0):
+        bits = counts.dtype.itemsize * 8
+        ok, oc = self.empty(kmers.n, np.uint64), self.empty(kmers.n, counts.dtype)
+        n = C.c_uint64(0)
+        self._check(self.lib.zk_trim(self.h, kmers.ptr, counts.ptr, bits, kmers.n, int(lo), int(hi), ok.ptr, oc.ptr, kmers.n, C.byref(n)))
+        return ok.view(n.value), oc.view(n.value)
+
+    def synth_reads(self, seed, first, count, L, genome=0, sub_thr=0, n_thr=0, out=None):
+        out = out if out is not None else self.empty(count * (L + 1), np.uint8)
+        self._check(self.lib.zk_synth_reads(self.h, int(seed), int(first), int(count), int(L), int(genome), int(sub_thr), int(n_thr), out.ptr))
+        return out
+
+    def checksum(self, kmers, counts=None):
+        s = (C.c_uint64 * 3)()
+        self._check(self.lib.zk_checksum(self.h, kmers.ptr, counts.ptr if counts is not None else None, kmers.n, s))
+        return tuple(int(v) for v in s)
+
+    def stream_checksum(self, stream, K):
+        s = (C.c_uint64 * 3)()
+        self._check(self.lib.zk_stream_checksum(self.h, stream.ptr, stream.n, K, s))
+        return tuple(int(v) for v in s)
