@@ -59,6 +59,22 @@ int zk_upload(zk_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 int zk_download(zk_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
 int zk_copy(zk_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes);   /* device to device, async */
 
+/* Per-launch timing with HIP events recorded on the ctx's own stream (what bench.py's roofline
+ * figure is computed from).  Tags name the kernels. */
+#define ZK_PROF_HIST_STREAM 1   /* digit histogram straight from the base stream */
+#define ZK_PROF_HIST_ARRAY 2
+#define ZK_PROF_PASS_STREAM 3   /* radix pass 0: encode in LDS + scatter            (8 B written per key) */
+#define ZK_PROF_PASS_KEYS 4     /* radix pass over a key array                      (16 B per key)        */
+#define ZK_PROF_PASS_PAIRS 5    /* radix pass over (key, u32) pairs                 (24 B per key)        */
+#define ZK_PROF_RLE 6
+#define ZK_PROF_UNION 7
+#define ZK_PROF_SELECT 8
+#define ZK_PROF_MIRROR 9
+#define ZK_PROF_INTERSECT 10
+#define ZK_PROF_COUNT_HIST 11
+int zk_profile(zk_ctx* ctx, int enable);   /* clears the records; enable != 0 starts recording */
+int zk_profile_read(zk_ctx* ctx, int tag, uint64_t* launches, double* total_ms, uint64_t* algorithmic_bytes);
+
 /* ---- K1/K2: encode ------------------------------------------------------------------------- */
 
 /* reads given as bases[offs[r] .. offs[r+1]) -> base stream (d_stream holds offs[n_reads] + n_reads

@@ -57,6 +57,19 @@ int arena_require(zk_ctx* c, uint64_t want, uint64_t must) {
     return ZK_OK;
 }
 
+void prof_begin(zk_ctx* c, int tag, uint64_t bytes) {
+    if (!c->profile) return;
+    zk_ctx::ProfRec r;
+    r.tag = tag; r.bytes = bytes;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { c->profile = false; return; }
+    (void)hipEventRecord(r.a, c->stream);
+    c->prof.push_back(r);
+}
+void prof_end(zk_ctx* c) {
+    if (!c->profile || c->prof.empty()) return;
+    (void)hipEventRecord(c->prof.back().b, c->stream);
+}
+
 int lookback_begin(zk_ctx* c, uint64_t words, uint32_t tiles, u32* epoch, u32* ticket_base) {
     if (words > c->status_words) {
         ZK_HIP(c, hipStreamSynchronize(c->stream));
@@ -130,6 +143,7 @@ void zk_destroy(zk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (c->arena) (void)hipFree(c->arena);
     if (c->status) (void)hipFree(c->status);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
@@ -178,6 +192,32 @@ int zk_mem_info(zk_ctx* c, uint64_t* free_bytes, uint64_t* total_bytes) {
     ZK_HIP(c, hipMemGetInfo(&f, &t));
     if (free_bytes) *free_bytes = f;
     if (total_bytes) *total_bytes = t;
+    return ZK_OK;
+}
+
+int zk_profile(zk_ctx* c, int enable) {
+    if (!c) return ZK_EINVAL;
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    c->prof.clear();
+    c->profile = enable != 0;
+    return ZK_OK;
+}
+
+int zk_profile_read(zk_ctx* c, int tag, uint64_t* launches, double* total_ms, uint64_t* total_bytes) {
+    if (!c) return ZK_EINVAL;
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    uint64_t n = 0, bytes = 0;
+    double ms = 0;
+    for (auto& r : c->prof) {
+        if (r.tag != tag) continue;
+        float t = 0;
+        ZK_HIP(c, hipEventElapsedTime(&t, r.a, r.b));
+        n++; ms += t; bytes += r.bytes;
+    }
+    if (launches) *launches = n;
+    if (total_ms) *total_ms = ms;
+    if (total_bytes) *total_bytes = bytes;
     return ZK_OK;
 }
 

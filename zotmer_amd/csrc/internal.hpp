@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "../../include/zotk.h"
 #include "common.hpp"
@@ -31,6 +32,11 @@ struct zk_ctx {
     u64* h_scalars = nullptr;  // pinned mirror
 
     std::string last_error;
+
+    // optional per-launch timing with HIP events on this stream (zk_profile_*)
+    struct ProfRec { int tag; uint64_t bytes; hipEvent_t a, b; };
+    bool profile = false;
+    std::vector<ProfRec> prof;
 };
 
 namespace zk {
@@ -56,6 +62,10 @@ int arena_require(zk_ctx* c, uint64_t want, uint64_t must);
 int lookback_begin(zk_ctx* c, uint64_t words, uint32_t tiles, u32* epoch, u32* ticket_base);
 // read and clear the device error word (after a stream sync); maps it to a ZK_E* code
 int check_device_error(zk_ctx* c);
+
+// per-launch timing: bracket a launch with prof_begin / prof_end (no-ops unless enabled)
+void prof_begin(zk_ctx* c, int tag, uint64_t algorithmic_bytes);
+void prof_end(zk_ctx* c);
 
 static inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 

@@ -83,7 +83,9 @@ int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, dou
             ZK_TRY(arena_alloc(c, 8 * uc, (void**)&rk2));
             ZK_TRY(arena_alloc(c, 4 * uc, (void**)&rv));
             ZK_TRY(arena_alloc(c, 4 * uc, (void**)&rv2));
+            prof_begin(c, ZK_PROF_MIRROR, 24 * uc);
             hipLaunchKernelGGL(mirror_kernel, dim3(ew_grid(c, uc)), dim3(256), 0, c->stream, sorted, cnt, (u64)uc, K, rk, rv);
+            prof_end(c);
             ZK_HIP(c, hipGetLastError());
             u64* sk; u32* sv;
             ZK_TRY(sort_pairs(c, rk, rk2, rv, rv2, uc, 2 * K, &sk, &sv));

@@ -373,7 +373,10 @@ static int launch_pass(zk_ctx* c, SortArgs a) {
     a.status = c->status;
     a.ticket = c->d_ticket;
     a.err = c->d_err;
+    prof_begin(c, SRC == SRC_STREAM ? ZK_PROF_PASS_STREAM : (PAIRS ? ZK_PROF_PASS_PAIRS : ZK_PROF_PASS_KEYS),
+               SRC == SRC_STREAM ? a.n_bytes + 8 * a.n : (PAIRS ? 24 : 16) * a.n);
     hipLaunchKernelGGL((pass_kernel<SORT_BLOCK, SORT_ITEMS, SRC, PAIRS>), dim3(tiles), dim3(SORT_BLOCK), 0, c->stream, a);
+    prof_end(c);
     ZK_HIP(c, hipGetLastError());
     return ZK_OK;
 }
@@ -390,7 +393,9 @@ static int launch_hist(zk_ctx* c, const SortArgs& src, const PassPlan& plan, u64
     if (acgt) ZK_HIP(c, hipMemsetAsync(acgt, 0, sizeof(u64) * 4, c->stream));
     u32 grid = h.tiles < (u32)(c->num_cus * 8) ? h.tiles : (u32)(c->num_cus * 8);
     if (grid == 0) grid = 1;
+    prof_begin(c, SRC == SRC_STREAM ? ZK_PROF_HIST_STREAM : ZK_PROF_HIST_ARRAY, SRC == SRC_STREAM ? src.n_bytes : 8 * src.n);
     hipLaunchKernelGGL((hist_kernel<SORT_BLOCK, SORT_ITEMS, SRC>), dim3(grid), dim3(SORT_BLOCK), 0, c->stream, h);
+    prof_end(c);
     ZK_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(hist_scan_kernel, dim3(1), dim3(SORT_RADIX), 0, c->stream, ghist, plan.passes, d_n);
     ZK_HIP(c, hipGetLastError());
@@ -464,9 +469,9 @@ int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_
     if (n > cap) return fail(c, ZK_ENOSPC, "sort buffers hold %llu keys, the stream has %llu", (unsigned long long)cap, (unsigned long long)n);
     if (n == 0) return ZK_OK;
     a.kout = buf_a; a.shift = plan.shift[0]; a.bits = plan.bits[0]; a.ghist = ghist;
+    a.n = n;
     ZK_TRY((launch_pass<SRC_STREAM, false>(c, a)));
     u64* in = buf_a; u64* out = buf_b;
-    a.n = n;
     for (int p = 1; p < plan.passes; p++) {
         a.kin = in; a.kout = out; a.shift = plan.shift[p]; a.bits = plan.bits[p];
         a.ghist = ghist + p * SORT_RADIX;

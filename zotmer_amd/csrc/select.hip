@@ -165,7 +165,9 @@ int rle(zk_ctx* c, const u64* sorted, uint64_t n, u64* uniq, u32* counts, uint64
     ZK_TRY(arena_alloc(c, sizeof(u32) * st.tiles, (void**)&lead));
     ZK_TRY(lookback_begin(c, st.tiles, st.tiles, &st.epoch, &st.ticket_base));
     st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9;
+    prof_begin(c, ZK_PROF_RLE, 8 * n);
     hipLaunchKernelGGL(rle_kernel, dim3(st.tiles), dim3(SEL_BLOCK), 0, c->stream, sorted, (u64)n, uniq, counts, (u64)cap, lead, st);
+    prof_end(c);
     ZK_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(rle_fixup_kernel, dim3((u32)div_up(st.tiles, 256)), dim3(256), 0, c->stream, lead, c->status, st.tiles,
                        counts, (u64)cap, c->d_err);
@@ -263,7 +265,9 @@ static int run_select(zk_ctx* c, const Op& op, uint64_t n, uint64_t cap, uint64_
     st.tiles = (u32)div_up(n, SEL_TILE);
     ZK_TRY(lookback_begin(c, st.tiles, st.tiles, &st.epoch, &st.ticket_base));
     st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9;
+    prof_begin(c, ZK_PROF_SELECT, sizeof(typename Op::R) * n);
     hipLaunchKernelGGL((select_kernel<Op>), dim3(st.tiles), dim3(SEL_BLOCK), 0, c->stream, op, (u64)n, (u64)cap, st);
+    prof_end(c);
     ZK_HIP(c, hipGetLastError());
     ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, c->d_scalars + 9, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
@@ -399,10 +403,12 @@ int count_hist(zk_ctx* c, const void* counts, int count_bits, uint64_t n, uint64
     ZK_HIP(c, hipMemsetAsync(dense, 0, sizeof(u64) * HIST_DENSE, c->stream));
     ZK_HIP(c, hipMemsetAsync(big_n, 0, sizeof(u64), c->stream));
     u32 grid = (u32)(div_up(n, 256 * 16) < (uint64_t)c->num_cus * 8 ? div_up(n, 256 * 16) : (uint64_t)c->num_cus * 8);
+    prof_begin(c, ZK_PROF_COUNT_HIST, (count_bits / 8) * n);
     if (count_bits == 32)
         hipLaunchKernelGGL((count_hist_kernel<u32>), dim3(grid), dim3(256), 0, c->stream, (const u32*)counts, (u64)n, dense, big, (u64)big_cap, big_n);
     else
         hipLaunchKernelGGL((count_hist_kernel<u64>), dim3(grid), dim3(256), 0, c->stream, (const u64*)counts, (u64)n, dense, big, (u64)big_cap, big_n);
+    prof_end(c);
     ZK_HIP(c, hipGetLastError());
     std::vector<u64> hd(HIST_DENSE);
     u64* h_dense = hd.data();

@@ -242,8 +242,10 @@ static int union_sum_t(zk_ctx* c, const u64* A, const CT* cA, u64 nA, const u64*
         d_acgt = c->d_scalars + 0;
         ZK_HIP(c, hipMemsetAsync(d_acgt, 0, 4 * sizeof(u64), c->stream));
     }
+    prof_begin(c, ZK_PROF_UNION, (8 + sizeof(CT)) * (nA + nB));
     hipLaunchKernelGGL((union_sum_kernel<CT>), dim3(tiles), dim3(MRG_BLOCK), 0, c->stream, A, cA, nA, B, cB, nB, part, ok, oc,
                        (u64)cap, d_acgt, st);
+    prof_end(c);
     ZK_HIP(c, hipGetLastError());
     ZK_HIP(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(u64) * 16, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
@@ -266,7 +268,9 @@ int intersect_count(zk_ctx* c, const u64* A, u64 nA, const u64* B, u64 nB, uint6
     ZK_TRY(make_partition(c, A, nA, B, nB, &part, &tiles));
     u64* d_n = c->d_scalars + 11;
     ZK_HIP(c, hipMemsetAsync(d_n, 0, sizeof(u64), c->stream));
+    prof_begin(c, ZK_PROF_INTERSECT, 8 * (nA + nB));
     hipLaunchKernelGGL(intersect_kernel, dim3(tiles), dim3(MRG_BLOCK), 0, c->stream, A, nA, B, nB, part, d_n);
+    prof_end(c);
     ZK_HIP(c, hipGetLastError());
     ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 11, d_n, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));

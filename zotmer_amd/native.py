@@ -53,6 +53,8 @@ SIGNATURES = {
     "zk_upload": (_i, [_vp, _vp, _vp, _u64]),
     "zk_download": (_i, [_vp, _vp, _vp, _u64]),
     "zk_copy": (_i, [_vp, _vp, _vp, _u64]),
+    "zk_profile": (_i, [_vp, _i]),
+    "zk_profile_read": (_i, [_vp, _i, _pu64, C.POINTER(C.c_double), _pu64]),
     "zk_pack_reads": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "zk_encode": (_i, [_vp, _vp, _u64, _i, _i, _vp, _u64, _pu64, _pu64]),
     "zk_subsample": (_i, [_vp, _vp, _u64, _u64, _d, _vp, _u64, _pu64]),
@@ -183,6 +185,23 @@ class Context:
         """bytes / uint8 array -> device base stream (zk_alloc memory is 256-byte aligned)."""
         a = np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray, memoryview)) else np.asarray(data, np.uint8)
         return self.upload(a)
+
+    # ---- per-launch timing (HIP events on the ctx stream) -----------------------------------
+    PROF_TAGS = {"hist_stream": 1, "hist_array": 2, "pass_stream": 3, "pass_keys": 4, "pass_pairs": 5, "rle": 6,
+                 "union_sum": 7, "select": 8, "mirror": 9, "intersect": 10, "count_hist": 11}
+
+    def profile(self, enable=True):
+        self._check(self.lib.zk_profile(self.h, int(enable)))
+
+    def profile_read(self):
+        """{kernel: dict(launches, ms, bytes)} for everything recorded since profile(True)."""
+        out = {}
+        for name, tag in self.PROF_TAGS.items():
+            n, b, ms = C.c_uint64(0), C.c_uint64(0), C.c_double(0)
+            self._check(self.lib.zk_profile_read(self.h, tag, C.byref(n), C.byref(ms), C.byref(b)))
+            if n.value:
+                out[name] = dict(launches=n.value, ms=ms.value, bytes=b.value)
+        return out
 
     # ---- kernels ------------------------------------------------------------------------------
     def pack_reads(self, bases, offs):
