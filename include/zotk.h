@@ -59,6 +59,10 @@ int zk_upload(zk_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 int zk_download(zk_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
 int zk_copy(zk_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes);   /* device to device, async */
 
+/* Tuning knobs (performance only; results never depend on them). */
+#define ZK_TUNE_SORT_VARIANT 1   /* radix-sort geometry index, see radix_sort.hip */
+int zk_tune(zk_ctx* ctx, int what, int value);
+
 /* Per-launch timing with HIP events recorded on the ctx's own stream (what bench.py's roofline
  * figure is computed from).  Tags name the kernels. */
 #define ZK_PROF_HIST_STREAM 1   /* digit histogram straight from the base stream */

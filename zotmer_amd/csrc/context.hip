@@ -195,6 +195,12 @@ int zk_mem_info(zk_ctx* c, uint64_t* free_bytes, uint64_t* total_bytes) {
     return ZK_OK;
 }
 
+int zk_tune(zk_ctx* c, int what, int value) {
+    if (!c) return ZK_EINVAL;
+    if (what == ZK_TUNE_SORT_VARIANT) { c->sort_variant = value; return ZK_OK; }
+    return fail(c, ZK_EINVAL, "unknown tuning knob %d", what);
+}
+
 int zk_profile(zk_ctx* c, int enable) {
     if (!c) return ZK_EINVAL;
     ZK_HIP(c, hipStreamSynchronize(c->stream));

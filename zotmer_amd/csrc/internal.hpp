@@ -14,6 +14,7 @@ struct zk_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cus = 256;
+    int sort_variant = 6;      // radix-sort geometry (zk_tune); 6 = 512 threads x 16 keys, 9-bit digits
 
     // workspace arena: a bump allocator reset at the start of every API call
     char* arena = nullptr;

@@ -18,19 +18,29 @@
 // windows vanish without a compaction pass (dead items are simply not ranked).
 //
 // Algorithmic bytes per key per pass: 8 read + 8 written (+4/+4 with a 32-bit payload).
+//
+// The geometry (threads per workgroup, keys per thread, digit bits) is a compile-time Cfg; a few
+// are instantiated and zk_tune(ZK_TUNE_SORT_VARIANT) picks one (default chosen from
+// measurements on MI355X).
 #include "internal.hpp"
 #include "encode_tile.hpp"
 
 namespace zk {
 
-constexpr int SORT_BLOCK = 512;
-constexpr int SORT_ITEMS = 16;
-constexpr int SORT_RBITS = 8;
-constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;
-constexpr int SORT_RADIX = 1 << SORT_RBITS;
 constexpr int MAX_PASSES = 8;
+constexpr int MAX_RADIX = 1024;
 
 enum { SRC_ARRAY = 0, SRC_STREAM = 1 };
+
+template <int BLOCK_, int ITEMS_, int RBITS_>
+struct Cfg {
+    static constexpr int BLOCK = BLOCK_, ITEMS = ITEMS_, RBITS = RBITS_;
+    static constexpr int TILE = BLOCK * ITEMS, RADIX = 1 << RBITS, NW = BLOCK / 64;
+    static constexpr int DPT = (RADIX + BLOCK - 1) / BLOCK;   // digits per thread in the per-digit steps
+    static_assert(ITEMS % 2 == 0 && 2 * ITEMS < 256, "ITEMS");
+    static_assert(64 * ITEMS < 65536, "per-wave ranks are 16-bit");
+    static_assert(RADIX <= MAX_RADIX && RBITS * MAX_PASSES >= 64, "RBITS");
+};
 
 struct PassPlan {
     int passes;
@@ -38,11 +48,11 @@ struct PassPlan {
     int bits[MAX_PASSES];
 };
 
-static PassPlan make_plan(int key_bits) {
+static PassPlan make_plan(int key_bits, int rbits) {
     PassPlan p;
     if (key_bits < 1) key_bits = 1;
     if (key_bits > 64) key_bits = 64;
-    p.passes = (key_bits + SORT_RBITS - 1) / SORT_RBITS;
+    p.passes = (key_bits + rbits - 1) / rbits;
     int base = key_bits / p.passes, rem = key_bits % p.passes, s = 0;
     for (int i = 0; i < MAX_PASSES; i++) { p.shift[i] = 0; p.bits[i] = 0; }
     for (int i = 0; i < p.passes; i++) {
@@ -84,11 +94,10 @@ struct SortArgs {
 //           emitted: items [0, ITEMS/2) are x, items [ITEMS/2, ITEMS) the matching rc(x))
 // acgt (COUNT only): four 8-bit counters packed in a word, acgt[b] in byte b -- at most 2*ITEMS
 // increments per call, so they cannot carry into each other.
-template <int BLOCK, int ITEMS, int SRC, bool PAIRS, bool COUNT>
-__device__ __forceinline__ u32 load_tile(const SortArgs& a, u32 tile, TileImage<BLOCK * ITEMS>* img,
-                                         u64 (&key)[ITEMS], u32 (&val)[ITEMS], u32& acgt) {
-    static_assert(2 * ITEMS < 256, "packed acgt counters are 8 bits");
-    constexpr int TILE = BLOCK * ITEMS;
+template <class C, int SRC, bool PAIRS, bool COUNT>
+__device__ __forceinline__ u32 load_tile(const SortArgs& a, u32 tile, TileImage<C::TILE>* img, u64 (&key)[C::ITEMS],
+                                         u32 (&val)[C::ITEMS], u32& acgt) {
+    constexpr int TILE = C::TILE, ITEMS = C::ITEMS, BLOCK = C::BLOCK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     u32 live = 0;
     if (SRC == SRC_ARRAY) {
@@ -155,34 +164,33 @@ struct HistArgs {
     u32 tiles;
 };
 
-template <int BLOCK, int ITEMS, int SRC>
-__global__ __launch_bounds__(BLOCK) void hist_kernel(HistArgs h) {
-    constexpr int TILE = BLOCK * ITEMS;
-    __shared__ u32 bins[MAX_PASSES][SORT_RADIX];
-    __shared__ TileImage<TILE> img;
-    for (int i = threadIdx.x; i < MAX_PASSES * SORT_RADIX; i += BLOCK) (&bins[0][0])[i] = 0;
+template <class C, int SRC>
+__global__ __launch_bounds__(C::BLOCK) void hist_kernel(HistArgs h) {
+    __shared__ u32 bins[MAX_PASSES * C::RADIX];
+    __shared__ TileImage<C::TILE> img;
+    for (int i = threadIdx.x; i < MAX_PASSES * C::RADIX; i += C::BLOCK) bins[i] = 0;
     u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     __syncthreads();
     for (u32 tile = blockIdx.x; tile < h.tiles; tile += gridDim.x) {
-        u64 key[ITEMS];
-        u32 val[ITEMS];
+        u64 key[C::ITEMS];
+        u32 val[C::ITEMS];
         u32 pk = 0;
-        u32 live = load_tile<BLOCK, ITEMS, SRC, false, SRC == SRC_STREAM>(h.src, tile, &img, key, val, pk);
+        u32 live = load_tile<C, SRC, false, SRC == SRC_STREAM>(h.src, tile, &img, key, val, pk);
         a0 += pk & 0xffu; a1 += (pk >> 8) & 0xffu; a2 += (pk >> 16) & 0xffu; a3 += pk >> 24;
 #pragma unroll
-        for (int i = 0; i < ITEMS; i++) {
+        for (int i = 0; i < C::ITEMS; i++) {
             if ((live >> i) & 1u) {
                 for (int p = 0; p < h.plan.passes; p++) {
                     u32 d = (u32)(key[i] >> h.plan.shift[p]) & ((1u << h.plan.bits[p]) - 1u);
-                    atomicAdd(&bins[p][d], 1u);
+                    atomicAdd(&bins[p * C::RADIX + d], 1u);
                 }
             }
         }
         if (SRC == SRC_STREAM) __syncthreads();   // img is restaged by the next iteration
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < h.plan.passes * SORT_RADIX; i += BLOCK) {
-        u32 v = (&bins[0][0])[i];
+    for (int i = threadIdx.x; i < h.plan.passes * C::RADIX; i += C::BLOCK) {
+        u32 v = bins[i];
         if (v) atomicAdd(&h.ghist[i], (u64)v);
     }
     if (h.acgt) {
@@ -197,18 +205,33 @@ __global__ __launch_bounds__(BLOCK) void hist_kernel(HistArgs h) {
 }
 
 // exclusive prefix over the digits of every pass, in place; total key count to *n_out
-__global__ void hist_scan_kernel(u64* ghist, int passes, u64* n_out) {
-    __shared__ u64 wsum[SORT_RADIX / 64];
-    const int d = threadIdx.x;   // blockDim.x == RADIX
+// one workgroup of 256 threads; radix up to MAX_RADIX
+__global__ void hist_scan_kernel(u64* ghist, int passes, int radix, u64* n_out) {
+    __shared__ u64 wsum[4];
+    const int t = threadIdx.x;
+    const int per = radix / 256 > 0 ? radix / 256 : 1;   // radix is a power of two
     for (int p = 0; p < passes; p++) {
-        u64 v = ghist[p * SORT_RADIX + d];
-        u64 inc = wave_incl_scan_u64(v);
-        if ((d & 63) == 63) wsum[d >> 6] = inc;
+        u64 v[MAX_RADIX / 256];
+        u64 s = 0;
+#pragma unroll
+        for (int j = 0; j < MAX_RADIX / 256; j++) {
+            const int d = t * per + j;
+            v[j] = (j < per && d < radix) ? ghist[p * radix + d] : 0;
+            s += v[j];
+        }
+        u64 inc = wave_incl_scan_u64(s);
+        if ((t & 63) == 63) wsum[t >> 6] = inc;
         __syncthreads();
         u64 off = 0;
-        for (int w = 0; w < (d >> 6); w++) off += wsum[w];
-        ghist[p * SORT_RADIX + d] = off + inc - v;
-        if (p == 0 && d == SORT_RADIX - 1) *n_out = off + inc;
+        for (int w = 0; w < (t >> 6); w++) off += wsum[w];
+        u64 run = off + inc - s;
+#pragma unroll
+        for (int j = 0; j < MAX_RADIX / 256; j++) {
+            const int d = t * per + j;
+            if (j < per && d < radix) ghist[p * radix + d] = run;
+            run += v[j];
+        }
+        if (p == 0 && t == 255) *n_out = off + inc;
         __syncthreads();
     }
 }
@@ -216,27 +239,24 @@ __global__ void hist_scan_kernel(u64* ghist, int passes, u64* n_out) {
 // ---------------------------------------------------------------------------------------
 // one pass
 // ---------------------------------------------------------------------------------------
-template <int BLOCK, int ITEMS, int SRC, bool PAIRS>
+template <class C>
 struct PassSmem {
-    static constexpr int TILE = BLOCK * ITEMS;
-    static constexpr int NW = BLOCK / 64;
     union {
-        u64 exch[TILE];
-        TileImage<TILE> img;
+        u64 exch[C::TILE];
+        TileImage<C::TILE> img;
     };
-    u32 cnt[NW][SORT_RADIX];
-    u32 digit_off[SORT_RADIX];
-    u64 gbase[SORT_RADIX];
-    u32 wsum[NW];
+    u16 cnt[C::NW][C::RADIX];
+    u32 digit_off[C::RADIX];
+    u64 gbase[C::RADIX];
+    u32 wsum[C::NW];
     u32 ticket;
     u32 total_live;
 };
 
-template <int BLOCK, int ITEMS, int SRC, bool PAIRS>
-__global__ __launch_bounds__(BLOCK) void pass_kernel(SortArgs a) {
-    constexpr int NW = BLOCK / 64;
-    static_assert(SORT_RADIX <= BLOCK, "one digit per thread");
-    __shared__ PassSmem<BLOCK, ITEMS, SRC, PAIRS> sm;
+template <class C, int SRC, bool PAIRS>
+__global__ __launch_bounds__(C::BLOCK) void pass_kernel(SortArgs a) {
+    constexpr int BLOCK = C::BLOCK, ITEMS = C::ITEMS, RADIX = C::RADIX, NW = C::NW, DPT = C::DPT;
+    __shared__ PassSmem<C> sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     const u32 tile = take_ticket(a.ticket, &sm.ticket) - a.ticket_base;
@@ -244,11 +264,11 @@ __global__ __launch_bounds__(BLOCK) void pass_kernel(SortArgs a) {
     u64 key[ITEMS];
     u32 val[ITEMS];
     u32 unused = 0;
-    const u32 live = load_tile<BLOCK, ITEMS, SRC, PAIRS, false>(a, tile, &sm.img, key, val, unused);
+    const u32 live = load_tile<C, SRC, PAIRS, false>(a, tile, &sm.img, key, val, unused);
 
     // ---- rank inside the wave ------------------------------------------------------------
-    u32* mycnt = sm.cnt[wave];
-    for (int d = lane; d < SORT_RADIX; d += 64) mycnt[d] = 0;
+    u16* mycnt = sm.cnt[wave];
+    for (int d = lane; d < RADIX; d += 64) mycnt[d] = 0;
     __syncthreads();
     const u32 dmask = (1u << a.bits) - 1u;
     u32 rank[ITEMS];
@@ -258,7 +278,7 @@ __global__ __launch_bounds__(BLOCK) void pass_kernel(SortArgs a) {
         const u32 d = (u32)(key[i] >> a.shift) & dmask;
         u64 peers = __ballot(lv);
 #pragma unroll
-        for (int b = 0; b < SORT_RBITS; b++) {
+        for (int b = 0; b < C::RBITS; b++) {
             if (b < a.bits) {
                 const bool bit = (d >> b) & 1u;
                 const u64 m = __ballot(bit);
@@ -267,55 +287,69 @@ __global__ __launch_bounds__(BLOCK) void pass_kernel(SortArgs a) {
         }
         const u32 below = popc_below(peers);
         const u32 npeer = (u32)__popcll(peers);
-        const u32 pre = lv ? mycnt[d] : 0u;
+        const u32 pre = lv ? (u32)mycnt[d] : 0u;
         rank[i] = pre + below;
-        if (lv && below == npeer - 1) mycnt[d] = pre + npeer;   // highest peer lane updates
+        if (lv && below == npeer - 1) mycnt[d] = (u16)(pre + npeer);   // highest peer lane updates
     }
     __syncthreads();
 
     // ---- per digit: exclusive scan over the waves, tile total ---------------------------------
-    u32 tile_count = 0;
-    if (tid < SORT_RADIX) {
+    // thread t owns digits t*DPT .. t*DPT+DPT-1
+    u32 tcount[DPT];
+    u32 tsum = 0;
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
-            u32 t = sm.cnt[w][tid];
-            sm.cnt[w][tid] = tile_count;
-            tile_count += t;
+    for (int j = 0; j < DPT; j++) {
+        const int d = tid * DPT + j;
+        u32 acc = 0;
+        if (d < RADIX) {
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const u32 t = sm.cnt[w][d];
+                sm.cnt[w][d] = (u16)acc;
+                acc += t;
+            }
         }
+        tcount[j] = acc;
+        tsum += acc;
     }
-    // exclusive scan of tile_count over the digits (threads >= RADIX hold 0)
-    u32 inc = wave_incl_scan_u32(tile_count);
+    // exclusive scan over the digits
+    const u32 inc = wave_incl_scan_u32(tsum);
     if (lane == 63) sm.wsum[wave] = inc;
     __syncthreads();
     u32 woff = 0;
     for (int w = 0; w < wave; w++) woff += sm.wsum[w];
-    const u32 dig_excl = woff + inc - tile_count;
+    u32 dig_excl = woff + inc - tsum;
     if (tid == BLOCK - 1) sm.total_live = woff + inc;
 
     // ---- decoupled look-back, one chain per digit ----------------------------------------------
-    if (tid < SORT_RADIX) {
-        u64* st = a.status + (u64)tile * SORT_RADIX + tid;
-        u64 excl = 0;
-        if (tile == 0) {
-            st_agent(st, st_pack(ZK_ST_INCLUSIVE, a.epoch, tile_count));
-        } else {
-            st_agent(st, st_pack(ZK_ST_PARTIAL, a.epoch, tile_count));
-            const u64* q = st - SORT_RADIX;
-            for (u32 t = tile; t > 0; t--, q -= SORT_RADIX) {
-                u64 w = ld_agent(q);
-                int spins = 0;
-                while (st_state(w, a.epoch) == 0) {
-                    if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT); break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    w = ld_agent(q);
+#pragma unroll
+    for (int j = 0; j < DPT; j++) {
+        const int d = tid * DPT + j;
+        if (d < RADIX) {
+            u64* st = a.status + (u64)tile * RADIX + d;
+            u64 excl = 0;
+            if (tile == 0) {
+                st_agent(st, st_pack(ZK_ST_INCLUSIVE, a.epoch, tcount[j]));
+            } else {
+                st_agent(st, st_pack(ZK_ST_PARTIAL, a.epoch, tcount[j]));
+                const u64* q = st - RADIX;
+                for (u32 t = tile; t > 0; t--, q -= RADIX) {
+                    u64 w = ld_agent(q);
+                    int spins = 0;
+                    while (st_state(w, a.epoch) == 0) {
+                        if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        w = ld_agent(q);
+                    }
+                    excl += w & ZK_ST_VALUE_MASK;
+                    if (st_state(w, a.epoch) != ZK_ST_PARTIAL) break;   // INCLUSIVE (or gave up)
                 }
-                excl += w & ZK_ST_VALUE_MASK;
-                if (st_state(w, a.epoch) != ZK_ST_PARTIAL) break;   // INCLUSIVE (or gave up)
+                st_agent(st, st_pack(ZK_ST_INCLUSIVE, a.epoch, excl + tcount[j]));
             }
-            st_agent(st, st_pack(ZK_ST_INCLUSIVE, a.epoch, excl + tile_count));
+            sm.digit_off[d] = dig_excl;
+            sm.gbase[d] = a.ghist[d] + excl - dig_excl;
+            dig_excl += tcount[j];
         }
-        sm.digit_off[tid] = dig_excl;
-        sm.gbase[tid] = a.ghist[tid] + excl - dig_excl;
     }
     __syncthreads();
 
@@ -359,92 +393,154 @@ __global__ __launch_bounds__(BLOCK) void pass_kernel(SortArgs a) {
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-static u32 tiles_for(const SortArgs& a, int src) {
-    if (src == SRC_ARRAY) return (u32)div_up(a.n, SORT_TILE);
-    const u64 pos = (a.mode == ZK_KEYS_BOTH) ? SORT_TILE / 2 : SORT_TILE;
-    return (u32)div_up(a.n_bytes, pos);
-}
+template <class C>
+struct Sorter {
+    static u32 tiles_for(const SortArgs& a, int src) {
+        if (src == SRC_ARRAY) return (u32)div_up(a.n, C::TILE);
+        const u64 pos = (a.mode == ZK_KEYS_BOTH) ? C::TILE / 2 : C::TILE;
+        return (u32)div_up(a.n_bytes, pos);
+    }
 
-template <int SRC, bool PAIRS>
-static int launch_pass(zk_ctx* c, SortArgs a) {
-    const u32 tiles = tiles_for(a, SRC);
-    if (tiles == 0) return ZK_OK;
-    ZK_TRY(lookback_begin(c, (uint64_t)tiles * SORT_RADIX, tiles, &a.epoch, &a.ticket_base));
-    a.status = c->status;
-    a.ticket = c->d_ticket;
-    a.err = c->d_err;
-    prof_begin(c, SRC == SRC_STREAM ? ZK_PROF_PASS_STREAM : (PAIRS ? ZK_PROF_PASS_PAIRS : ZK_PROF_PASS_KEYS),
-               SRC == SRC_STREAM ? a.n_bytes + 8 * a.n : (PAIRS ? 24 : 16) * a.n);
-    hipLaunchKernelGGL((pass_kernel<SORT_BLOCK, SORT_ITEMS, SRC, PAIRS>), dim3(tiles), dim3(SORT_BLOCK), 0, c->stream, a);
-    prof_end(c);
-    ZK_HIP(c, hipGetLastError());
-    return ZK_OK;
-}
+    template <int SRC, bool PAIRS>
+    static int launch_pass(zk_ctx* c, SortArgs a) {
+        const u32 tiles = tiles_for(a, SRC);
+        if (tiles == 0) return ZK_OK;
+        ZK_TRY(lookback_begin(c, (uint64_t)tiles * C::RADIX, tiles, &a.epoch, &a.ticket_base));
+        a.status = c->status;
+        a.ticket = c->d_ticket;
+        a.err = c->d_err;
+        prof_begin(c, SRC == SRC_STREAM ? ZK_PROF_PASS_STREAM : (PAIRS ? ZK_PROF_PASS_PAIRS : ZK_PROF_PASS_KEYS),
+                   SRC == SRC_STREAM ? a.n_bytes + 8 * a.n : (PAIRS ? 24 : 16) * a.n);
+        hipLaunchKernelGGL((pass_kernel<C, SRC, PAIRS>), dim3(tiles), dim3(C::BLOCK), 0, c->stream, a);
+        prof_end(c);
+        ZK_HIP(c, hipGetLastError());
+        return ZK_OK;
+    }
 
-template <int SRC>
-static int launch_hist(zk_ctx* c, const SortArgs& src, const PassPlan& plan, u64* ghist, u64* acgt, u64* d_n) {
-    HistArgs h;
-    h.src = src;
-    h.plan = plan;
-    h.ghist = ghist;
-    h.acgt = acgt;
-    h.tiles = tiles_for(src, SRC);
-    ZK_HIP(c, hipMemsetAsync(ghist, 0, sizeof(u64) * MAX_PASSES * SORT_RADIX, c->stream));
-    if (acgt) ZK_HIP(c, hipMemsetAsync(acgt, 0, sizeof(u64) * 4, c->stream));
-    u32 grid = h.tiles < (u32)(c->num_cus * 8) ? h.tiles : (u32)(c->num_cus * 8);
-    if (grid == 0) grid = 1;
-    prof_begin(c, SRC == SRC_STREAM ? ZK_PROF_HIST_STREAM : ZK_PROF_HIST_ARRAY, SRC == SRC_STREAM ? src.n_bytes : 8 * src.n);
-    hipLaunchKernelGGL((hist_kernel<SORT_BLOCK, SORT_ITEMS, SRC>), dim3(grid), dim3(SORT_BLOCK), 0, c->stream, h);
-    prof_end(c);
-    ZK_HIP(c, hipGetLastError());
-    hipLaunchKernelGGL(hist_scan_kernel, dim3(1), dim3(SORT_RADIX), 0, c->stream, ghist, plan.passes, d_n);
-    ZK_HIP(c, hipGetLastError());
-    return ZK_OK;
-}
+    template <int SRC>
+    static int launch_hist(zk_ctx* c, const SortArgs& src, const PassPlan& plan, u64* ghist, u64* acgt, u64* d_n) {
+        HistArgs h;
+        h.src = src;
+        h.plan = plan;
+        h.ghist = ghist;
+        h.acgt = acgt;
+        h.tiles = tiles_for(src, SRC);
+        ZK_HIP(c, hipMemsetAsync(ghist, 0, sizeof(u64) * MAX_PASSES * C::RADIX, c->stream));
+        if (acgt) ZK_HIP(c, hipMemsetAsync(acgt, 0, sizeof(u64) * 4, c->stream));
+        u32 grid = h.tiles < (u32)(c->num_cus * 8) ? h.tiles : (u32)(c->num_cus * 8);
+        if (grid == 0) grid = 1;
+        prof_begin(c, SRC == SRC_STREAM ? ZK_PROF_HIST_STREAM : ZK_PROF_HIST_ARRAY, SRC == SRC_STREAM ? src.n_bytes : 8 * src.n);
+        hipLaunchKernelGGL((hist_kernel<C, SRC>), dim3(grid), dim3(C::BLOCK), 0, c->stream, h);
+        prof_end(c);
+        ZK_HIP(c, hipGetLastError());
+        hipLaunchKernelGGL(hist_scan_kernel, dim3(1), dim3(256), 0, c->stream, ghist, plan.passes, (int)C::RADIX, d_n);
+        ZK_HIP(c, hipGetLastError());
+        return ZK_OK;
+    }
+
+    static int sort_keys(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** result) {
+        PassPlan plan = make_plan(key_bits, C::RBITS);
+        u64* ghist;
+        ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * C::RADIX, (void**)&ghist));
+        SortArgs a = {};
+        a.kin = keys; a.n = n;
+        ZK_TRY(launch_hist<SRC_ARRAY>(c, a, plan, ghist, nullptr, c->d_scalars + 8));
+        u64* in = keys; u64* out = alt;
+        for (int p = 0; p < plan.passes; p++) {
+            a.kin = in; a.kout = out; a.shift = plan.shift[p]; a.bits = plan.bits[p];
+            a.ghist = ghist + p * C::RADIX;
+            ZK_TRY((launch_pass<SRC_ARRAY, false>(c, a)));
+            u64* t = in; in = out; out = t;
+        }
+        *result = in;
+        return ZK_OK;
+    }
+
+    static int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, u64** rk, u32** rv) {
+        PassPlan plan = make_plan(key_bits, C::RBITS);
+        u64* ghist;
+        ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * C::RADIX, (void**)&ghist));
+        SortArgs a = {};
+        a.kin = keys; a.n = n;
+        ZK_TRY(launch_hist<SRC_ARRAY>(c, a, plan, ghist, nullptr, c->d_scalars + 8));
+        u64* in = keys; u64* out = alt; u32* vi = vals; u32* vo = valt;
+        for (int p = 0; p < plan.passes; p++) {
+            a.kin = in; a.kout = out; a.vin = vi; a.vout = vo; a.shift = plan.shift[p]; a.bits = plan.bits[p];
+            a.ghist = ghist + p * C::RADIX;
+            ZK_TRY((launch_pass<SRC_ARRAY, true>(c, a)));
+            u64* t = in; in = out; out = t;
+            u32* tv = vi; vi = vo; vo = tv;
+        }
+        *rk = in; *rv = vi;
+        return ZK_OK;
+    }
+
+    // Sort the k-mers of a base stream without ever storing them unsorted: histogram and first
+    // pass read the stream, the remaining passes ping-pong between buf_a and buf_b.
+    static int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,
+                           uint64_t acgt[4], u64** result) {
+        PassPlan plan = make_plan(2 * src.K, C::RBITS);
+        u64* ghist;
+        ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * C::RADIX, (void**)&ghist));
+        SortArgs a = {};
+        a.stream = src.stream; a.n_bytes = src.n_bytes; a.K = src.K; a.mode = src.mode;
+        u64* d_acgt = c->d_scalars + 0;
+        u64* d_n = c->d_scalars + 8;
+        ZK_TRY(launch_hist<SRC_STREAM>(c, a, plan, ghist, d_acgt, d_n));
+        // the number of live keys decides the grids of the array passes: one small readback
+        ZK_HIP(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(u64) * 16, hipMemcpyDeviceToHost, c->stream));
+        ZK_HIP(c, hipStreamSynchronize(c->stream));
+        const uint64_t n = c->h_scalars[8];
+        if (acgt) for (int b = 0; b < 4; b++) acgt[b] = c->h_scalars[b];
+        *n_keys = n;
+        if (n > cap) return fail(c, ZK_ENOSPC, "sort buffers hold %llu keys, the stream has %llu", (unsigned long long)cap, (unsigned long long)n);
+        if (n == 0) return ZK_OK;
+        a.kout = buf_a; a.shift = plan.shift[0]; a.bits = plan.bits[0]; a.ghist = ghist;
+        a.n = n;
+        ZK_TRY((launch_pass<SRC_STREAM, false>(c, a)));
+        u64* in = buf_a; u64* out = buf_b;
+        for (int p = 1; p < plan.passes; p++) {
+            a.kin = in; a.kout = out; a.shift = plan.shift[p]; a.bits = plan.bits[p];
+            a.ghist = ghist + p * C::RADIX;
+            ZK_TRY((launch_pass<SRC_ARRAY, false>(c, a)));
+            u64* t = in; in = out; out = t;
+        }
+        *result = in;
+        return ZK_OK;
+    }
+};
+
+// the instantiated geometries; index = zk_tune(ZK_TUNE_SORT_VARIANT)
+typedef Cfg<512, 16, 8> V0;
+typedef Cfg<256, 16, 8> V1;
+typedef Cfg<256, 8, 8> V2;
+typedef Cfg<1024, 16, 8> V3;
+typedef Cfg<512, 8, 8> V4;
+typedef Cfg<1024, 8, 10> V5;
+typedef Cfg<512, 16, 9> V6;
+#define ZK_SORT_DISPATCH(c, CALL)                   \
+    switch ((c)->sort_variant) {                    \
+        case 1: return Sorter<V1>::CALL;            \
+        case 2: return Sorter<V2>::CALL;            \
+        case 3: return Sorter<V3>::CALL;            \
+        case 4: return Sorter<V4>::CALL;            \
+        case 5: return Sorter<V5>::CALL;            \
+        case 6: return Sorter<V6>::CALL;            \
+        default: return Sorter<V0>::CALL;           \
+    }
 
 int sort_keys(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** result) {
     *result = keys;
     if (n == 0) return ZK_OK;
-    PassPlan plan = make_plan(key_bits);
-    u64* ghist;
-    ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * SORT_RADIX, (void**)&ghist));
-    SortArgs a = {};
-    a.kin = keys; a.n = n;
-    ZK_TRY(launch_hist<SRC_ARRAY>(c, a, plan, ghist, nullptr, c->d_scalars + 8));
-    u64* in = keys; u64* out = alt;
-    for (int p = 0; p < plan.passes; p++) {
-        a.kin = in; a.kout = out; a.shift = plan.shift[p]; a.bits = plan.bits[p];
-        a.ghist = ghist + p * SORT_RADIX;
-        ZK_TRY((launch_pass<SRC_ARRAY, false>(c, a)));
-        u64* t = in; in = out; out = t;
-    }
-    *result = in;
-    return ZK_OK;
+    ZK_SORT_DISPATCH(c, sort_keys(c, keys, alt, n, key_bits, result));
 }
 
 int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, u64** rk, u32** rv) {
     *rk = keys; *rv = vals;
     if (n == 0) return ZK_OK;
-    PassPlan plan = make_plan(key_bits);
-    u64* ghist;
-    ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * SORT_RADIX, (void**)&ghist));
-    SortArgs a = {};
-    a.kin = keys; a.n = n;
-    ZK_TRY(launch_hist<SRC_ARRAY>(c, a, plan, ghist, nullptr, c->d_scalars + 8));
-    u64* in = keys; u64* out = alt; u32* vi = vals; u32* vo = valt;
-    for (int p = 0; p < plan.passes; p++) {
-        a.kin = in; a.kout = out; a.vin = vi; a.vout = vo; a.shift = plan.shift[p]; a.bits = plan.bits[p];
-        a.ghist = ghist + p * SORT_RADIX;
-        ZK_TRY((launch_pass<SRC_ARRAY, true>(c, a)));
-        u64* t = in; in = out; out = t;
-        u32* tv = vi; vi = vo; vo = tv;
-    }
-    *rk = in; *rv = vi;
-    return ZK_OK;
+    ZK_SORT_DISPATCH(c, sort_pairs(c, keys, alt, vals, valt, n, key_bits, rk, rv));
 }
 
-// Sort the k-mers of a base stream without ever storing them unsorted: histogram and first pass
-// read the stream, the remaining passes ping-pong between buf_a and buf_b (cap keys each).
 int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,
                 uint64_t acgt[4], u64** result) {
     *result = buf_a;
@@ -452,34 +548,7 @@ int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_
     if (acgt) acgt[0] = acgt[1] = acgt[2] = acgt[3] = 0;
     if (src.n_bytes == 0) return ZK_OK;
     if ((uintptr_t)src.stream & 15) return fail(c, ZK_EINVAL, "base stream must be 16-byte aligned");
-    PassPlan plan = make_plan(2 * src.K);
-    u64* ghist;
-    ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * SORT_RADIX, (void**)&ghist));
-    SortArgs a = {};
-    a.stream = src.stream; a.n_bytes = src.n_bytes; a.K = src.K; a.mode = src.mode;
-    u64* d_acgt = c->d_scalars + 0;
-    u64* d_n = c->d_scalars + 8;
-    ZK_TRY(launch_hist<SRC_STREAM>(c, a, plan, ghist, d_acgt, d_n));
-    // the number of live keys decides the grids of the array passes: one small readback
-    ZK_HIP(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(u64) * 16, hipMemcpyDeviceToHost, c->stream));
-    ZK_HIP(c, hipStreamSynchronize(c->stream));
-    const uint64_t n = c->h_scalars[8];
-    if (acgt) for (int b = 0; b < 4; b++) acgt[b] = c->h_scalars[b];
-    *n_keys = n;
-    if (n > cap) return fail(c, ZK_ENOSPC, "sort buffers hold %llu keys, the stream has %llu", (unsigned long long)cap, (unsigned long long)n);
-    if (n == 0) return ZK_OK;
-    a.kout = buf_a; a.shift = plan.shift[0]; a.bits = plan.bits[0]; a.ghist = ghist;
-    a.n = n;
-    ZK_TRY((launch_pass<SRC_STREAM, false>(c, a)));
-    u64* in = buf_a; u64* out = buf_b;
-    for (int p = 1; p < plan.passes; p++) {
-        a.kin = in; a.kout = out; a.shift = plan.shift[p]; a.bits = plan.bits[p];
-        a.ghist = ghist + p * SORT_RADIX;
-        ZK_TRY((launch_pass<SRC_ARRAY, false>(c, a)));
-        u64* t = in; in = out; out = t;
-    }
-    *result = in;
-    return ZK_OK;
+    ZK_SORT_DISPATCH(c, sort_stream(c, src, buf_a, buf_b, cap, n_keys, acgt, result));
 }
 
 }  // namespace zk

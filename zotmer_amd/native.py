@@ -53,6 +53,7 @@ SIGNATURES = {
     "zk_upload": (_i, [_vp, _vp, _vp, _u64]),
     "zk_download": (_i, [_vp, _vp, _vp, _u64]),
     "zk_copy": (_i, [_vp, _vp, _vp, _u64]),
+    "zk_tune": (_i, [_vp, _i, _i]),
     "zk_profile": (_i, [_vp, _i]),
     "zk_profile_read": (_i, [_vp, _i, _pu64, C.POINTER(C.c_double), _pu64]),
     "zk_pack_reads": (_i, [_vp, _vp, _vp, _u64, _vp]),
@@ -189,6 +190,10 @@ class Context:
     # ---- per-launch timing (HIP events on the ctx stream) -----------------------------------
     PROF_TAGS = {"hist_stream": 1, "hist_array": 2, "pass_stream": 3, "pass_keys": 4, "pass_pairs": 5, "rle": 6,
                  "union_sum": 7, "select": 8, "mirror": 9, "intersect": 10, "count_hist": 11}
+
+    def tune(self, sort_variant=None):
+        if sort_variant is not None:
+            self._check(self.lib.zk_tune(self.h, 1, int(sort_variant)))
 
     def profile(self, enable=True):
         self._check(self.lib.zk_profile(self.h, int(enable)))
