@@ -98,6 +98,13 @@ int zk_encode(zk_ctx* ctx, const uint8_t* d_stream, uint64_t n_bytes, int K, int
 int zk_subsample(zk_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint64_t seed, double p,
                  uint64_t* d_out, uint64_t cap, uint64_t* n_out);
 
+/* capture mode, `zot kmerize -C BAITS` (commands/kmerize.py:480-485,510-520): a read is kept iff one
+ * of its k-mers is in the sorted bait array (both strands of the bait sequences); reads without a hit
+ * are blanked ('N') in d_out, which then feeds zk_kmerize.  A read is a '\n'-terminated piece of the
+ * stream.  d_out holds n_bytes. */
+int zk_capture_filter(zk_ctx* ctx, const uint8_t* d_stream, uint64_t n_bytes, int K, const uint64_t* d_baits, uint64_t n_baits,
+                      uint8_t* d_out, uint64_t* n_reads, uint64_t* n_kept);
+
 /* ---- K3/K4: sort and count ------------------------------------------------------------------ */
 
 /* misc.radix_sort(key_bits, xs) (library/misc.py:400-424): ascending, in place. */
@@ -167,6 +174,27 @@ int zk_split(zk_ctx* ctx, const uint64_t* d_x, uint64_t nx, const uint64_t* d_y,
 int zk_trim(zk_ctx* ctx, const uint64_t* d_kmers, const void* d_counts, int count_bits, uint64_t n,
             uint64_t lo, uint64_t hi, uint64_t* d_ok, void* d_oc, uint64_t cap, uint64_t* n_out);
 
+/* ---- host-side format code (CPU; no ctx, no GPU): next-row f1/f2 of SURVEY.md section 8 ------------ */
+
+/* codec64.encode (library/codec64.py:42-120) over HOST arrays; delta != 0 first replaces ascending
+ * k-mers by their differences (files.delta, library/files.py:85-98).  ZK_ERANGE when a value or delta
+ * is >= 2^60 (the reference raises there).  words needs at most n entries. */
+int zk_codec64_encode(const uint64_t* vals, uint64_t n, int delta, uint64_t* words, uint64_t cap, uint64_t* n_words);
+/* sum of the tags = number of values in a word stream */
+int zk_codec64_count(const uint64_t* words, uint64_t nw, uint64_t* n_values);
+/* codec64.decode (library/codec64.py:122-151); delta != 0 also undoes the delta transform
+ * (files.undelta, library/files.py:100-110) */
+int zk_codec64_decode(const uint64_t* words, uint64_t nw, int delta, uint64_t* out, uint64_t cap, uint64_t* n_out);
+
+/* file.readFastq / file.readFasta (library/file.py:19-52) as chunked text -> base stream converters.
+ * state: 4 words, zero before the first chunk, state[1] = records seen.  Feed text; *consumed says how
+ * much was used (present the rest again in front of the next chunk); final != 0 on the last chunk.
+ * *out_len is read (append position) and updated. */
+int zk_parse_fastq(const char* buf, uint64_t len, int final, uint64_t state[4], uint8_t* out, uint64_t out_cap,
+                   uint64_t* out_len, uint64_t* consumed);
+int zk_parse_fasta(const char* buf, uint64_t len, int final, uint64_t state[4], uint8_t* out, uint64_t out_cap,
+                   uint64_t* out_len, uint64_t* consumed);
+
 /* ---- synthetic input (bench / tests) ------------------------------------- */
 
 /* Reads first .. first+count-1 of the counter-based generator (zotmer_amd/synth.py) as a base
@@ -179,8 +207,9 @@ int zk_synth_reads(zk_ctx* ctx, uint64_t seed, uint64_t first, uint64_t count, i
 int zk_checksum(zk_ctx* ctx, const uint64_t* d_kmers, const uint32_t* d_counts, uint64_t n, uint64_t sums[3]);
 
 /* the same three sums over every k-mer instance (x and rc(x) of each valid window) of a base
- * stream, computed straight from the stream without sorting anything */
-int zk_stream_checksum(zk_ctx* ctx, const uint8_t* d_stream, uint64_t n_bytes, int K, uint64_t sums[3]);
+ * stream, computed straight from the stream without sorting anything; sums[3..6] = acgt[x & 3]
+ * over the same instances (commands/kmerize.py:492-493) */
+int zk_stream_checksum(zk_ctx* ctx, const uint8_t* d_stream, uint64_t n_bytes, int K, uint64_t sums[7]);
 
 /* internal key-source selectors (shared with the kernels) */
 #define ZK_KEYS_FORWARD 0

@@ -1,0 +1,180 @@
+"""
+End-to-end `zot <command>` on the GPU against the files the reference wrote for the same inputs
+(tests/golden): the two codec64 payload streams must match byte for byte, the metadata value for
+value, and `zot dist` stdout character for character.
+"""
+import gzip
+import io
+import json
+import os
+import struct
+from contextlib import redirect_stdout
+
+import numpy as np
+import pytest
+
+from tests import _golden as G
+from zotmer_amd import cli
+from zotmer_amd.library import vectors
+from zotmer_amd.library.container import Container, KmerSet
+
+pytestmark = pytest.mark.gpu
+
+
+def zot(*args):
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        rc = cli.main_inner([str(a) for a in args])
+    return buf.getvalue(), rc
+
+
+def members(path):
+    with Container(str(path), "r") as z:
+        return {nm: z.read(nm) for nm, _ in z.names()}
+
+
+def check_file(path, name, meta_keys=("K", "hist", "acgt", "reads")):
+    info, km, ct, raw_k, raw_c = G.load_case(name)
+    m = members(path)
+    assert m["kmers"] == raw_k, "kmers stream differs from the reference's bytes"
+    assert m["counts"] == raw_c, "counts stream differs from the reference's bytes"
+    meta = json.loads(m["__meta__"].decode())
+    for k in meta_keys:
+        if k in info["meta"]:
+            assert meta[k] == info["meta"][k], k
+    assert meta["kmers"] == "kmers" and meta["counts"] == "counts"
+    return meta
+
+
+def write_case_fastq(tmp_path, name, fname="in.fastq"):
+    info = G.load_json(name)
+    p = tmp_path / fname
+    p.write_text(G.synth_fastq(info))
+    return info, p
+
+
+@pytest.mark.parametrize("name", G.KMERIZE_SYNTH_CASES)
+def test_kmerize_files(tmp_path, name):
+    info, fq = write_case_fastq(tmp_path, name)
+    out = tmp_path / "out.k"
+    zot("kmerize", info["K"], out, fq)
+    check_file(out, name)
+    # BASELINE.json's spelling, small device batches (several union-sum rounds), gz input
+    gz = tmp_path / "in2.fastq.gz"
+    with gzip.open(str(gz), "wb") as f:
+        f.write(fq.read_bytes())
+    out2 = tmp_path / "out2.k"
+    zot("kmerize", "-k", info["K"], "-m", "1", out2, gz)
+    assert members(out2)["kmers"] == members(out)["kmers"] and members(out2)["counts"] == members(out)["counts"]
+    check_file(out2, name)
+
+
+def test_kmerize_edge_inputs(tmp_path):
+    fq = tmp_path / "e.fastq"
+    fa = tmp_path / "e.fa"
+    fq.write_text(G.load_json("g9_edge_fastq")["fastq"])
+    fa.write_text(G.load_json("g9_edge_fasta")["fasta"])
+    zot("kmerize", 25, tmp_path / "a.k25", fq)
+    check_file(tmp_path / "a.k25", "g9_edge_fastq")
+    zot("kmerize", 25, tmp_path / "b.k25", fa)
+    check_file(tmp_path / "b.k25", "g9_edge_fasta")
+    zot("kmerize", 25, tmp_path / "c.k25", fq, fa)
+    check_file(tmp_path / "c.k25", "g9_two_files")
+
+
+def test_kmerize_subsample_and_capture(tmp_path):
+    info, fq = write_case_fastq(tmp_path, "g10_kmerize_D0.8_S3")
+    zot("kmerize", "-D", "0.8", "-S", "3", 25, tmp_path / "d.k25", fq)
+    check_file(tmp_path / "d.k25", "g10_kmerize_D0.8_S3")
+    cinfo = G.load_json("g10_kmerize_capture")
+    bait = tmp_path / "bait.fa"
+    bait.write_text(cinfo["bait_fasta"])
+    zot("kmerize", "-C", bait, 25, tmp_path / "c.k25", fq)
+    check_file(tmp_path / "c.k25", "g10_kmerize_capture")
+    zot("kmerize", "-C", bait, "-m", "1", 25, tmp_path / "c2.k25", fq)
+    check_file(tmp_path / "c2.k25", "g10_kmerize_capture")
+
+
+def test_kmerize_k31_overflow_raises(tmp_path):
+    fq = tmp_path / "t.fastq"
+    fq.write_text("@r0\n%s\n+\n%s\n" % ("T" * 31, "I" * 31))
+    with pytest.raises(vectors.CodecError):          # the reference dies here too (golden g8_k31_delta_overflow)
+        zot("kmerize", 31, tmp_path / "t.k31", fq)
+
+
+def make_set(tmp_path, name):
+    """Materialise a golden set as a container file."""
+    info, km, ct, _, _ = G.load_case(name)
+    p = tmp_path / (name + ".k25")
+    with KmerSet(str(p), "w") as z:
+        vectors.write_kmers_and_counts(z, km, ct)
+        z.meta.update(info["meta"])
+        z.meta.setdefault("K", 25)
+    return p
+
+
+def test_merge_files(tmp_path):
+    parts = [make_set(tmp_path, "g4_part%d" % i) for i in range(5)]
+    for n in (2, 3, 4, 5):
+        out = tmp_path / ("m%d.k25" % n)
+        zot("merge", out, *parts[:n])
+        meta = check_file(out, "g4_merge%d" % n, meta_keys=("hist",) if n <= 2 else ("K", "hist", "acgt"))
+        assert meta["K"] == 25 and "reads" not in meta
+    # mismatched K: message + exit status 1 (merge.py:186-190)
+    other = tmp_path / "k24.k24"
+    info, km, ct, _, _ = G.load_case("g3_kmerize_genome_k24")
+    with KmerSet(str(other), "w") as z:
+        vectors.write_kmers_and_counts(z, km, ct)
+        z.meta.update(info["meta"])
+    with pytest.raises(SystemExit) as e:
+        zot("merge", tmp_path / "bad.k", parts[0], other)
+    assert e.value.code == 1
+
+
+def test_dist_stdout(tmp_path):
+    g = G.load_json("g5_dist")
+    files = {n: make_set(tmp_path, n) for n in ("g4_part0", "g4_part1", "g4_part2", "g4_merge3")}
+    for key in ("qual_k25", "jaccard_k12", "mixed_k20"):
+        a = g[key]["args"]
+        argv = ["dist"]
+        for m in a["M"]:
+            argv += ["-M", m]
+        argv += [a["k"]] + [files[n] for n in a["inputs"]]
+        out, _ = zot(*argv)
+        ref = g[key]["stdout"]
+        # the reference printed its own temporary paths: map them to ours, in order of appearance
+        names = []
+        for row in (l.split("\t") for l in ref.strip().split("\n")[1:]):
+            for nm in row[:2]:
+                if nm not in names:
+                    names.append(nm)
+        for old, new in zip(names, [str(files[n]) for n in a["inputs"]]):
+            ref = ref.replace(old, new)
+        assert out == ref
+    out, _ = zot("dist", "-M", "list", 25)
+    assert out == g["list"]["stdout"]
+    out, _ = zot("dist", 25, files["g4_part0"], files["g4_part1"])       # no -M: prints nothing (dist.py:120-124)
+    assert out == ""
+
+
+def test_trim_files(tmp_path):
+    src = make_set(tmp_path, "g3_kmerize_genome")
+    zot("trim", "-c", 3, tmp_path / "t3.k25", src)
+    meta = check_file(tmp_path / "t3.k25", "g6_trim_c3")
+    assert meta["hist"] == G.load_json("g3_kmerize_genome")["meta"]["hist"]          # copied, not recomputed (trim.py:95)
+    zot("trim", "-c", 2, "-C", 9, tmp_path / "t29.k25", src)
+    check_file(tmp_path / "t29.k25", "g6_trim_c2_C9")
+
+
+def test_info_hist_dump(tmp_path):
+    src = make_set(tmp_path, "g9_edge_fastq")
+    out, _ = zot("info", src)
+    assert "K 25" in out.split("\n")
+    out, _ = zot("hist", src)
+    info, km, ct, _, _ = G.load_case("g9_edge_fastq")
+    assert out == "".join("%s\t%d\t%d\n" % (src, int(f), c) for f, c in sorted((int(f), c) for f, c in info["meta"]["hist"].items()))
+    out, _ = zot("dump", src)
+    from oracle import zkoracle as zo
+    assert out == "".join("%s\t%d\n" % (zo.render(25, int(k)), int(c)) for k, c in zip(km, ct))
+    _, rc = zot("nosuchcommand")
+    assert rc == 1

@@ -75,6 +75,7 @@ constexpr int CS_BLOCK = 256, CS_ITEMS = 8, CS_TILE = CS_BLOCK * CS_ITEMS;
 __global__ __launch_bounds__(CS_BLOCK) void stream_checksum_kernel(const u8* __restrict__ stream, u64 n_bytes, int K, u32 tiles, u64* sums) {
     __shared__ TileImage<CS_TILE> img;
     u64 s0 = 0, s1 = 0, s2 = 0;
+    u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     for (u32 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         stage_tile<CS_BLOCK, CS_TILE>(stream, n_bytes, (u64)tile * CS_TILE, img);
 #pragma unroll
@@ -83,12 +84,18 @@ __global__ __launch_bounds__(CS_BLOCK) void stream_checksum_kernel(const u8* __r
             if (window_at(img, (int)threadIdx.x + i * CS_BLOCK, K, x)) {
                 const u64 xb = revcomp(K, x);
                 s0 += 2; s1 += x + xb; s2 += murmer(x, 0) + murmer(xb, 0);
+                const u32 f = (u32)(x & 3), b = (u32)(xb & 3);
+                a0 += (f == 0) + (b == 0); a1 += (f == 1) + (b == 1); a2 += (f == 2) + (b == 2); a3 += (f == 3) + (b == 3);
             }
         }
         __syncthreads();
     }
     s0 = wave_sum_u64(s0); s1 = wave_sum_u64(s1); s2 = wave_sum_u64(s2);
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1); atomicAdd(&sums[2], s2); }
+    const u64 t0 = wave_sum_u64(a0), t1 = wave_sum_u64(a1), t2 = wave_sum_u64(a2), t3 = wave_sum_u64(a3);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1); atomicAdd(&sums[2], s2);
+        atomicAdd(&sums[3], t0); atomicAdd(&sums[4], t1); atomicAdd(&sums[5], t2); atomicAdd(&sums[6], t3);
+    }
 }
 
 static u32 grid_for(zk_ctx* c, u64 n, u64 per_block) {
@@ -248,18 +255,25 @@ int zk_checksum(zk_ctx* c, const uint64_t* d_kmers, const uint32_t* d_counts, ui
     return ZK_OK;
 }
 
-int zk_stream_checksum(zk_ctx* c, const uint8_t* d_stream, uint64_t n_bytes, int K, uint64_t sums[3]) {
+int zk_capture_filter(zk_ctx* c, const uint8_t* d_stream, uint64_t n_bytes, int K, const uint64_t* d_baits, uint64_t n_baits,
+                      uint8_t* d_out, uint64_t* n_reads, uint64_t* n_kept) {
+    ZK_ARGS(c, n_reads && n_kept && d_out && K >= 1 && K <= 32);
+    arena_reset(c);
+    return capture_filter(c, d_stream, n_bytes, K, (const u64*)d_baits, n_baits, d_out, n_reads, n_kept);
+}
+
+int zk_stream_checksum(zk_ctx* c, const uint8_t* d_stream, uint64_t n_bytes, int K, uint64_t sums[7]) {
     ZK_ARGS(c, sums && K >= 1 && K <= 32 && (((uintptr_t)d_stream) & 15) == 0);
     u64* d = c->d_scalars + 12;
-    ZK_HIP(c, hipMemsetAsync(d, 0, 3 * sizeof(u64), c->stream));
+    ZK_HIP(c, hipMemsetAsync(d, 0, 7 * sizeof(u64), c->stream));
     if (n_bytes) {
         const u32 tiles = (u32)div_up(n_bytes, CS_TILE);
         hipLaunchKernelGGL(stream_checksum_kernel, dim3(grid_for(c, tiles, 1)), dim3(CS_BLOCK), 0, c->stream, d_stream, (u64)n_bytes, K, tiles, d);
         ZK_HIP(c, hipGetLastError());
     }
-    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 12, d, 3 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 12, d, 7 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 3; i++) sums[i] = c->h_scalars[12 + i];
+    for (int i = 0; i < 7; i++) sums[i] = c->h_scalars[12 + i];
     return ZK_OK;
 }
 

@@ -87,6 +87,8 @@ int subsample(zk_ctx* c, const u64* keys, uint64_t n, u64 seed, double p, u64* o
 int subsample_pairs(zk_ctx* c, u64* keys, u32* cnts, uint64_t n, u64 seed, double p, uint64_t* n_out);   // in place
 int encode_list(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int both, u64* out, uint64_t cap, uint64_t* n_out,
                 uint64_t acgt[4]);
+int capture_filter(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, const u64* baits, uint64_t n_baits, u8* out,
+                   uint64_t* n_reads, uint64_t* n_kept);
 int rle(zk_ctx* c, const u64* sorted, uint64_t n, u64* uniq, u32* counts, uint64_t cap, uint64_t* n_unique);
 int count_hist(zk_ctx* c, const void* counts, int count_bits, uint64_t n, uint64_t* vals, uint64_t* freq,
                uint64_t cap_bins, uint64_t* n_bins);

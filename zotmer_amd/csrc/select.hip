@@ -367,6 +367,95 @@ int encode_list(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int both, 
 }
 
 // ---------------------------------------------------------------------------------------
+// K2b: capture mode, `zot kmerize -C BAITS` (commands/kmerize.py:480-485,510-520): a read
+// contributes ALL its k-mers iff any one of them is in the bait set B (both strands of the bait
+// sequences).  Done as a filter on the base stream: reads without a hit are blanked (every byte
+// becomes 'N'), after which the normal pipeline runs on the filtered stream.  B is strand-symmetric,
+// so testing the forward k-mer of each window is enough.
+// ---------------------------------------------------------------------------------------
+struct NewlineOp {       // positions of the read terminators
+    const u8* stream; u64* out;
+    struct R { u64 idx; };
+    __device__ bool load(u64 idx, R& r) const { r.idx = idx; return stream[idx] == '\n'; }
+    __device__ void store(u64 pos, const R& r) const { out[pos] = r.idx; }
+};
+
+constexpr int CAP_TILE = SEL_BLOCK * SEL_ITEMS;
+__global__ __launch_bounds__(SEL_BLOCK) void bait_hit_kernel(const u8* __restrict__ stream, u64 n_bytes, int K,
+                                                             const u64* __restrict__ baits, u64 n_baits, u8* __restrict__ hit,
+                                                             u32 tiles) {
+    __shared__ TileImage<CAP_TILE> img;
+    for (u32 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const u64 t0 = (u64)tile * CAP_TILE;
+        stage_tile<SEL_BLOCK, CAP_TILE>(stream, n_bytes, t0, img);
+#pragma unroll
+        for (int i = 0; i < SEL_ITEMS; i++) {
+            const int p = (int)threadIdx.x + i * SEL_BLOCK;
+            u64 x;
+            u8 h = 0;
+            if (window_at(img, p, K, x)) {
+                u64 lo = 0, hi = n_baits;
+                while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (baits[mid] < x) lo = mid + 1; else hi = mid; }
+                h = (lo < n_baits && baits[lo] == x) ? 1 : 0;
+            }
+            if (t0 + p < n_bytes) hit[t0 + p] = h;
+        }
+        __syncthreads();
+    }
+}
+
+// one wave per read: OR of the hits over the read; blank the read in `out` when there is none
+__global__ void capture_apply_kernel(const u8* __restrict__ stream, const u8* __restrict__ hit, const u64* __restrict__ ends,
+                                     u64 n_reads, u8* __restrict__ out, u64* n_kept) {
+    const u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const u64 nw = ((u64)gridDim.x * blockDim.x) >> 6;
+    u64 kept = 0;
+    for (u64 r = wave; r < n_reads; r += nw) {
+        const u64 b = r ? ends[r - 1] + 1 : 0, e = ends[r];
+        bool any = false;
+        for (u64 i = b + lane; i < e; i += 64) any |= hit[i] != 0;
+        const bool keep = __ballot(any) != 0;
+        for (u64 i = b + lane; i < e; i += 64) out[i] = keep ? stream[i] : (u8)'N';
+        if (lane == 0) { out[e] = '\n'; kept += keep ? 1 : 0; }
+    }
+    if (lane == 0 && kept) atomicAdd(n_kept, kept);
+}
+
+int capture_filter(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, const u64* baits, uint64_t n_baits, u8* out,
+                   uint64_t* n_reads, uint64_t* n_kept) {
+    *n_reads = 0; *n_kept = 0;
+    if (n_bytes == 0) return ZK_OK;
+    if ((uintptr_t)stream & 15) return fail(c, ZK_EINVAL, "base stream must be 16-byte aligned");
+    u8* hit; u64* ends;
+    ZK_TRY(arena_require(c, 9 * n_bytes + (1 << 20), 9 * n_bytes + (1 << 20)));
+    ZK_TRY(arena_alloc(c, n_bytes, (void**)&hit));
+    ZK_TRY(arena_alloc(c, 8 * n_bytes, (void**)&ends));
+    const u32 tiles = (u32)div_up(n_bytes, CAP_TILE);
+    const u32 grid = tiles < (u32)c->num_cus * 8 ? tiles : (u32)c->num_cus * 8;
+    hipLaunchKernelGGL(bait_hit_kernel, dim3(grid), dim3(SEL_BLOCK), 0, c->stream, stream, (u64)n_bytes, K, baits, (u64)n_baits, hit, tiles);
+    ZK_HIP(c, hipGetLastError());
+    NewlineOp op{stream, ends};
+    uint64_t nr = 0;
+    ZK_TRY(run_select(c, op, n_bytes, n_bytes, &nr));
+    *n_reads = nr;
+    // bytes after the last terminator (a stream that does not end in '\n') belong to no read: copy them
+    ZK_HIP(c, hipMemcpyAsync(out, stream, n_bytes, hipMemcpyDeviceToDevice, c->stream));
+    u64* d_kept = c->d_scalars + 11;
+    ZK_HIP(c, hipMemsetAsync(d_kept, 0, sizeof(u64), c->stream));
+    if (nr) {
+        u64 g = div_up(nr, 4);
+        if (g > (u64)c->num_cus * 16) g = (u64)c->num_cus * 16;
+        hipLaunchKernelGGL(capture_apply_kernel, dim3((u32)g), dim3(256), 0, c->stream, stream, hit, ends, (u64)nr, out, d_kept);
+        ZK_HIP(c, hipGetLastError());
+    }
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 11, d_kept, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    *n_kept = c->h_scalars[11];
+    return check_device_error(c);
+}
+
+// ---------------------------------------------------------------------------------------
 // K7: histogram of counts.  Values below HIST_DENSE go to LDS bins; the (rare) larger ones are
 // appended to a list that the host folds in.
 // ---------------------------------------------------------------------------------------

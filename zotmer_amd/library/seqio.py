@@ -1,0 +1,102 @@
+"""
+Sequence text -> base-stream batches for the GPU.
+
+Reference: zotmer/library/reads.py:11-33,86-98 (file type by name suffix, FASTA else FASTQ) and
+zotmer/library/file.py:19-52,79-123 (line parsers; .gz / .bz2 inputs are decompressed on the fly --
+the reference pipes them through `gunzip -c` / `bunzip2 -c`, here Python's gzip / bz2 modules do it).
+
+A base stream is every sequence of the batch followed by '\\n' (see include/zotk.h).  Parsing is done
+by the native chunk parsers in libzotk.so (csrc/hostio.cpp); this module only moves bytes.
+"""
+import bz2
+import ctypes as C
+import gzip
+import sys
+
+import numpy as np
+
+from zotmer_amd import native
+
+_COMPRESSION = (".gz", ".bz2")
+_FASTA = (".fa", ".fasta", ".fas", ".fna")
+
+
+def strip_compression_suffix(name):
+    for s in _COMPRESSION:
+        if name.endswith(s):
+            return name[:-len(s)]
+    return name
+
+
+def is_fasta(name):
+    return strip_compression_suffix(name).endswith(_FASTA)
+
+
+def open_binary(name):
+    if name == "-":
+        return sys.stdin.buffer
+    if name.endswith(".gz"):
+        return gzip.open(name, "rb")
+    if name.endswith(".bz2"):
+        return bz2.open(name, "rb")
+    return open(name, "rb")
+
+
+def base_stream_batches(paths, batch_bytes=256 << 20, chunk_bytes=32 << 20):
+    """Yield (uint8 array holding a base stream, number of records in it) over all input files, in
+    order; a batch never splits a record."""
+    lib = native.load()
+    out = np.empty(batch_bytes + chunk_bytes + 16, dtype=np.uint8)
+    out_len = C.c_uint64(0)
+    recs_in_batch = 0
+    for path in paths:
+        parse = lib.zk_parse_fasta if is_fasta(path) else lib.zk_parse_fastq
+        state = (C.c_uint64 * 4)(0, 0, 0, 0)
+        carry = b""
+        with open_binary(path) as f:
+            final = False
+            while not final:
+                data = f.read(chunk_bytes)
+                final = len(data) < chunk_bytes
+                if not final:
+                    # peek: an exact multiple of the chunk size still needs a final call
+                    pass
+                buf = carry + data
+                if not data:
+                    final = True
+                pos = 0
+                while True:
+                    if out_len.value + (len(buf) - pos) + 2 > out.size:
+                        # flush what we have, then continue with the same text
+                        if out_len.value:
+                            yield out[:out_len.value].copy(), recs_in_batch
+                            out_len.value = 0
+                            recs_in_batch = 0
+                        if (len(buf) - pos) + 2 > out.size:
+                            out = np.empty(len(buf) - pos + chunk_bytes, dtype=np.uint8)
+                    before = state[1]
+                    consumed = C.c_uint64(0)
+                    view = memoryview(buf)[pos:]
+                    cbuf = (C.c_char * len(view)).from_buffer_copy(view) if len(view) else None
+                    rc = parse(cbuf, len(view), int(final), state, out.ctypes.data, out.size, C.byref(out_len), C.byref(consumed))
+                    recs_in_batch += state[1] - before
+                    pos += consumed.value
+                    if rc == native.ZK_OK:
+                        break
+                    if rc != native.ZK_ENOSPC:
+                        raise IOError("parse error %d in %s" % (rc, path))
+                carry = buf[pos:]
+                if out_len.value >= batch_bytes:
+                    yield out[:out_len.value].copy(), recs_in_batch
+                    out_len.value = 0
+                    recs_in_batch = 0
+    if out_len.value or recs_in_batch:
+        yield out[:out_len.value].copy(), recs_in_batch
+
+
+def fasta_sequences(path):
+    """The sequences of a (small) FASTA file as bytes objects -- used for bait files."""
+    seqs = []
+    for stream, _ in base_stream_batches([path]):
+        seqs.extend(bytes(stream).split(b"\n")[:-1])
+    return seqs

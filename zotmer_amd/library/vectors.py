@@ -1,0 +1,91 @@
+"""
+Vector members of a k-mer set: numpy arrays <-> codec64 word streams, through the native codec in
+libzotk.so (csrc/hostio.cpp).  Reference: zotmer/library/files.py:54-227 -- k-mers are stored as the
+codec64 words of their deltas (first delta from 0), counts as the codec64 words of the raw values,
+words back to back as little-endian uint64 with no header.
+"""
+import ctypes as C
+
+import numpy as np
+
+from zotmer_amd import native
+
+
+class CodecError(ValueError):
+    pass
+
+
+def _enc(values, delta):
+    a = np.ascontiguousarray(values, dtype=np.uint64)
+    words = np.empty(max(a.size, 1), dtype=np.uint64)
+    n = C.c_uint64(0)
+    rc = native.load().zk_codec64_encode(a.ctypes.data, a.size, int(delta), words.ctypes.data, words.size, C.byref(n))
+    if rc == native.ZK_ERANGE:
+        # the reference dies here too (IndexError / struct.error, codec64.py:33-40, files.py:65-83)
+        raise CodecError("a value (or k-mer delta) >= 2**60 cannot be stored in the codec64 format")
+    if rc != native.ZK_OK:
+        raise CodecError("codec64 encode failed (%d)" % rc)
+    return words[:n.value]
+
+
+def _dec(data, delta):
+    words = np.frombuffer(data, dtype="<u8")
+    lib = native.load()
+    n = C.c_uint64(0)
+    rc = lib.zk_codec64_count(words.ctypes.data, words.size, C.byref(n))
+    if rc != native.ZK_OK:
+        raise CodecError("corrupt codec64 stream (unknown tag)")
+    out = np.empty(max(n.value, 1), dtype=np.uint64)
+    m = C.c_uint64(0)
+    rc = lib.zk_codec64_decode(words.ctypes.data, words.size, int(delta), out.ctypes.data, out.size, C.byref(m))
+    if rc != native.ZK_OK:
+        raise CodecError("codec64 decode failed (%d)" % rc)
+    return out[:m.value]
+
+
+def encode_kmers(kmers):
+    """ascending uint64 k-mers -> bytes of the 'kmers' member (files.writeKmers, files.py:143-147)"""
+    return _enc(kmers, True).astype("<u8", copy=False).tobytes()
+
+
+def encode_counts(counts):
+    """counts -> bytes of the 'counts' member (files.writeCounts, files.py:155-156)"""
+    return _enc(counts, False).astype("<u8", copy=False).tobytes()
+
+
+def decode_kmers(data):
+    """bytes of a 'kmers' member -> uint64 k-mers (files.readKmers, files.py:152-153)"""
+    return _dec(data, True)
+
+
+def decode_counts(data):
+    """bytes of a 'counts' member -> uint64 counts (files.readCounts, files.py:158-159)"""
+    return _dec(data, False)
+
+
+def read_kmers(z, name=None):
+    """k-mers of a set (files.readKmers, files.py:152-153)"""
+    return decode_kmers(z.read((name + "-kmers") if name else "kmers"))
+
+
+def read_kmers_and_counts(z, name=None):
+    """(kmers, counts) of a k-mer set (files.readKmersAndCounts, files.py:219-227)"""
+    if name:
+        kn, cn = name + "-kmers", name + "-counts"
+    else:
+        kn, cn = "kmers", "counts"
+    k = decode_kmers(z.read(kn))
+    c = decode_counts(z.read(cn))
+    if len(k) != len(c):
+        raise CodecError("k-mer and count vectors differ in length (%d vs %d)" % (len(k), len(c)))
+    return k, c
+
+
+def write_kmers_and_counts(z, kmers, counts, name=None):
+    """files.writeKmersAndCounts2 (files.py:209-217): member order kmers, then counts"""
+    if name:
+        kn, cn = name + "-kmers", name + "-counts"
+    else:
+        kn, cn = "kmers", "counts"
+    z.add(kn, encode_kmers(kmers))
+    z.add(cn, encode_counts(counts))

@@ -58,6 +58,7 @@ SIGNATURES = {
     "zk_profile_read": (_i, [_vp, _i, _pu64, C.POINTER(C.c_double), _pu64]),
     "zk_pack_reads": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "zk_encode": (_i, [_vp, _vp, _u64, _i, _i, _vp, _u64, _pu64, _pu64]),
+    "zk_capture_filter": (_i, [_vp, _vp, _u64, _i, _vp, _u64, _vp, _pu64, _pu64]),
     "zk_subsample": (_i, [_vp, _vp, _u64, _u64, _d, _vp, _u64, _pu64]),
     "zk_sort_keys": (_i, [_vp, _vp, _u64, _i]),
     "zk_sort_pairs": (_i, [_vp, _vp, _vp, _u64, _i]),
@@ -71,6 +72,11 @@ SIGNATURES = {
     "zk_project_dedupe": (_i, [_vp, _vp, _u64, _i, _vp, _u64, _pu64]),
     "zk_split": (_i, [_vp, _vp, _u64, _vp, _u64, _pu64]),
     "zk_trim": (_i, [_vp, _vp, _vp, _i, _u64, _u64, _u64, _vp, _vp, _u64, _pu64]),
+    "zk_codec64_encode": (_i, [_vp, _u64, _i, _vp, _u64, _pu64]),
+    "zk_codec64_count": (_i, [_vp, _u64, _pu64]),
+    "zk_codec64_decode": (_i, [_vp, _u64, _i, _vp, _u64, _pu64]),
+    "zk_parse_fastq": (_i, [_vp, _u64, _i, _pu64, _vp, _u64, _pu64, _pu64]),
+    "zk_parse_fasta": (_i, [_vp, _u64, _i, _pu64, _vp, _u64, _pu64, _pu64]),
     "zk_synth_reads": (_i, [_vp, _u64, _u64, _u64, _i, _u64, _u32, _u32, _vp]),
     "zk_checksum": (_i, [_vp, _vp, _vp, _u64, _pu64]),
     "zk_stream_checksum": (_i, [_vp, _vp, _u64, _i, _pu64]),
@@ -338,6 +344,18 @@ class Context:
         return tuple(int(v) for v in s)
 
     def stream_checksum(self, stream, K):
-        s = (C.c_uint64 * 3)()
+        s = (C.c_uint64 * 7)()
         self._check(self.lib.zk_stream_checksum(self.h, stream.ptr, stream.n, K, s))
-        return tuple(int(v) for v in s)
+        return tuple(int(v) for v in s[:3])
+
+    def stream_acgt(self, stream, K):
+        """acgt[x & 3] over every k-mer instance of the stream (commands/kmerize.py:492-493)"""
+        s = (C.c_uint64 * 7)()
+        self._check(self.lib.zk_stream_checksum(self.h, stream.ptr, stream.n, K, s))
+        return [int(v) for v in s[3:7]]
+
+    def capture_filter(self, stream, K, baits):
+        out = self.empty(stream.n, np.uint8)
+        nr, nk = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.lib.zk_capture_filter(self.h, stream.ptr, stream.n, K, baits.ptr, baits.n, out.ptr, C.byref(nr), C.byref(nk)))
+        return out, nr.value, nk.value
