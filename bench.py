@@ -105,17 +105,24 @@ def main():
     # distinct k-mers: 2 strands x (genome + ~21 novel windows per substitution); leave headroom
     est_unique = int(2 * (min(cfg["genome"], R * L) + R * L * cfg["sub"] * 22) * 1.25) + (1 << 20)
     cap = min(est_unique, 2 * n_bytes)
-    out_k, out_c = ctx.empty(cap, np.uint64), ctx.empty(cap, np.uint32)
-
     par = None
     if world > 1:
+        # the exchange goes through torch.distributed, so the table lives in torch tensors that the
+        # library writes through their data_ptr() (uint64 carried as int64, uint32 as int32)
+        import torch
         from zotmer_amd import parallel
+        kt = torch.empty(cap, dtype=torch.int64, device="cuda")
+        ct = torch.empty(cap, dtype=torch.int32, device="cuda")
+        out_k = native.DeviceArray.borrow(ctx, kt.data_ptr(), np.uint64, cap, keep=kt)
+        out_c = native.DeviceArray.borrow(ctx, ct.data_ptr(), np.uint32, cap, keep=ct)
         par = parallel.RangeExchange(ctx, dist, K)
+    else:
+        out_k, out_c = ctx.empty(cap, np.uint64), ctx.empty(cap, np.uint32)
 
     def step():
         k, c, st = ctx.kmerize(stream, K, flags, out=(out_k, out_c))
         if par is not None:
-            k, c = par.exchange_and_merge(k, c)
+            k, c = par.exchange_and_merge(kt, ct, k.n)
         h = ctx.hist(c)
         return k, c, st, h
 

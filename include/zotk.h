@@ -60,7 +60,8 @@ int zk_download(zk_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
 int zk_copy(zk_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes);   /* device to device, async */
 
 /* Tuning knobs (performance only; results never depend on them). */
-#define ZK_TUNE_SORT_VARIANT 1   /* radix-sort geometry index, see radix_sort.hip */
+#define ZK_TUNE_SORT_VARIANT 1   /* radix-sort geometry index for key arrays, see radix_sort.hip */
+#define ZK_TUNE_PAIRS_VARIANT 2  /* ... for (key, payload) pairs */
 int zk_tune(zk_ctx* ctx, int what, int value);
 
 /* Per-launch timing with HIP events recorded on the ctx's own stream (what bench.py's roofline
@@ -167,6 +168,10 @@ int zk_project_dedupe(zk_ctx* ctx, const uint64_t* d_kmers, uint64_t n, int shif
                       uint64_t* d_out, uint64_t cap, uint64_t* n_out);
 /* dist.split (library/dist.py:241-265): abc = (|X & Y|, |X \ Y|, |Y \ X|) of two sorted unique arrays. */
 int zk_split(zk_ctx* ctx, const uint64_t* d_x, uint64_t nx, const uint64_t* d_y, uint64_t ny, uint64_t abc[3]);
+
+/* positions[q] = how many elements of the sorted device array are < queries[q] (HOST arrays of m
+ * entries): the cut points of a value-range partition for the multi-GPU exchange. */
+int zk_lower_bound(zk_ctx* ctx, const uint64_t* d_sorted, uint64_t n, const uint64_t* queries, uint32_t m, uint64_t* positions);
 
 /* ---- K10: trim ---------------------------------------------------------------------------------- */
 

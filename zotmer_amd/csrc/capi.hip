@@ -98,6 +98,16 @@ __global__ __launch_bounds__(CS_BLOCK) void stream_checksum_kernel(const u8* __r
     }
 }
 
+// positions[q] = number of elements of the sorted array that are < queries[q]
+__global__ void lower_bound_kernel(const u64* __restrict__ a, u64 n, const u64* __restrict__ q, u32 m, u64* __restrict__ pos) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m) return;
+    const u64 x = q[t];
+    u64 lo = 0, hi = n;
+    while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (a[mid] < x) lo = mid + 1; else hi = mid; }
+    pos[t] = lo;
+}
+
 static u32 grid_for(zk_ctx* c, u64 n, u64 per_block) {
     u64 g = div_up(n, per_block), mx = (u64)c->num_cus * 16;
     return (u32)(g < mx ? (g ? g : 1) : mx);
@@ -229,6 +239,21 @@ int zk_trim(zk_ctx* c, const uint64_t* d_kmers, const void* d_counts, int count_
     ZK_ARGS(c, n_out && (count_bits == 32 || count_bits == 64));
     arena_reset(c);
     return trim(c, (const u64*)d_kmers, d_counts, count_bits, n, lo, hi, (u64*)d_ok, d_oc, cap, n_out);
+}
+
+int zk_lower_bound(zk_ctx* c, const uint64_t* d_sorted, uint64_t n, const uint64_t* queries, uint32_t m, uint64_t* positions) {
+    ZK_ARGS(c, (m == 0) || (queries && positions));
+    if (m == 0) return ZK_OK;
+    arena_reset(c);
+    u64 *dq, *dp;
+    ZK_TRY(arena_alloc(c, 8ull * m, (void**)&dq));
+    ZK_TRY(arena_alloc(c, 8ull * m, (void**)&dp));
+    ZK_HIP(c, hipMemcpyAsync(dq, queries, 8ull * m, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(lower_bound_kernel, dim3((m + 63) / 64), dim3(64), 0, c->stream, (const u64*)d_sorted, (u64)n, dq, m, dp);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(positions, dp, 8ull * m, hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    return ZK_OK;
 }
 
 int zk_synth_reads(zk_ctx* c, uint64_t seed, uint64_t first, uint64_t count, int L, uint64_t genome, uint32_t sub_thr,

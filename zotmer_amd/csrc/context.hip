@@ -57,6 +57,19 @@ int arena_require(zk_ctx* c, uint64_t want, uint64_t must) {
     return ZK_OK;
 }
 
+int aux_require(zk_ctx* c, uint64_t bytes, char** p) {
+    if (bytes > c->aux_size) {
+        ZK_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->aux) { ZK_HIP(c, hipFree(c->aux)); c->aux = nullptr; c->aux_size = 0; }
+        const uint64_t want = (bytes + bytes / 16 + 4095) & ~4095ull;
+        hipError_t e = hipMalloc((void**)&c->aux, want);
+        if (e != hipSuccess) return fail(c, ZK_ENOMEM, "hipMalloc(%llu) for the mirror buffers failed: %s", (unsigned long long)want, hipGetErrorString(e));
+        c->aux_size = want;
+    }
+    *p = c->aux;
+    return ZK_OK;
+}
+
 void prof_begin(zk_ctx* c, int tag, uint64_t bytes) {
     if (!c->profile) return;
     zk_ctx::ProfRec r;
@@ -145,6 +158,7 @@ void zk_destroy(zk_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (c->arena) (void)hipFree(c->arena);
+    if (c->aux) (void)hipFree(c->aux);
     if (c->status) (void)hipFree(c->status);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
     if (c->d_err) (void)hipFree(c->d_err);
@@ -198,6 +212,7 @@ int zk_mem_info(zk_ctx* c, uint64_t* free_bytes, uint64_t* total_bytes) {
 int zk_tune(zk_ctx* c, int what, int value) {
     if (!c) return ZK_EINVAL;
     if (what == ZK_TUNE_SORT_VARIANT) { c->sort_variant = value; return ZK_OK; }
+    if (what == ZK_TUNE_PAIRS_VARIANT) { c->pairs_variant = value; return ZK_OK; }
     return fail(c, ZK_EINVAL, "unknown tuning knob %d", what);
 }
 

@@ -14,12 +14,18 @@ struct zk_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cus = 256;
-    int sort_variant = 6;      // radix-sort geometry (zk_tune); 6 = 512 threads x 16 keys, 9-bit digits
+    int sort_variant = 6;      // radix-sort geometry for key arrays (zk_tune); 6 = 512 threads x 16 keys, 9-bit digits
+    int pairs_variant = 0;     // ... for (key, u32) pairs; 0 = 512 x 16, 8-bit digits (fewer registers with the payload)
 
     // workspace arena: a bump allocator reset at the start of every API call
     char* arena = nullptr;
     uint64_t arena_size = 0;
     uint64_t arena_off = 0;
+
+    // second, grow-only region for buffers whose size is known only mid-call (the mirror step of
+    // zk_kmerize): keeps the arena from having to be sized for the worst case
+    char* aux = nullptr;
+    uint64_t aux_size = 0;
 
     // decoupled look-back state (persistent: cleared once per 31 launches, see common.hpp)
     u64* status = nullptr;
@@ -59,6 +65,7 @@ int fail(zk_ctx* c, int code, const char* fmt, ...);
 void arena_reset(zk_ctx* c);
 int arena_alloc(zk_ctx* c, uint64_t bytes, void** p);   // 256-byte aligned; grows the arena when idle
 int arena_require(zk_ctx* c, uint64_t want, uint64_t must);
+int aux_require(zk_ctx* c, uint64_t bytes, char** p);   // grows (free + malloc) when too small
 // look-back state for one launch that needs `words` status words and `tiles` tickets
 int lookback_begin(zk_ctx* c, uint64_t words, uint32_t tiles, u32* epoch, u32* ticket_base);
 // read and clear the device error word (after a stream sync); maps it to a ZK_E* code

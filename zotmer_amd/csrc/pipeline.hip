@@ -56,7 +56,7 @@ int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, dou
     const uint64_t cap_keys = both ? 2 * n_bytes : n_bytes;   // one window per stream byte at most
     arena_reset(c);
     const uint64_t slack = (1 << 20) + cap_keys / 16;
-    ZK_TRY(arena_require(c, 16 * cap_keys + (both ? 0 : 24 * cap_keys) + slack, 16 * cap_keys + slack));
+    ZK_TRY(arena_require(c, 16 * cap_keys + slack, 16 * cap_keys + slack));
     u64 *buf_a, *buf_b;
     ZK_TRY(arena_alloc(c, 8 * cap_keys, (void**)&buf_a));
     ZK_TRY(arena_alloc(c, 8 * cap_keys, (void**)&buf_b));
@@ -78,11 +78,11 @@ int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, dou
         ZK_TRY(rle(c, sorted, n, sorted, cnt, n, &uc));     // in place: sorted[0..uc) = distinct canonical k-mers
         st->n_canonical = uc;
         if (uc) {
-            u64 *rk, *rk2; u32 *rv, *rv2;
-            ZK_TRY(arena_alloc(c, 8 * uc, (void**)&rk));
-            ZK_TRY(arena_alloc(c, 8 * uc, (void**)&rk2));
-            ZK_TRY(arena_alloc(c, 4 * uc, (void**)&rv));
-            ZK_TRY(arena_alloc(c, 4 * uc, (void**)&rv2));
+            const uint64_t a8 = (8 * uc + 255) & ~255ull, a4 = (4 * uc + 255) & ~255ull;
+            char* aux;
+            ZK_TRY(aux_require(c, 2 * a8 + 2 * a4, &aux));
+            u64* rk = (u64*)aux; u64* rk2 = (u64*)(aux + a8);
+            u32* rv = (u32*)(aux + 2 * a8); u32* rv2 = (u32*)(aux + 2 * a8 + a4);
             prof_begin(c, ZK_PROF_MIRROR, 24 * uc);
             hipLaunchKernelGGL(mirror_kernel, dim3(ew_grid(c, uc)), dim3(256), 0, c->stream, sorted, cnt, (u64)uc, K, rk, rv);
             prof_end(c);

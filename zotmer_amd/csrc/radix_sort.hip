@@ -518,8 +518,9 @@ typedef Cfg<1024, 16, 8> V3;
 typedef Cfg<512, 8, 8> V4;
 typedef Cfg<1024, 8, 10> V5;
 typedef Cfg<512, 16, 9> V6;
-#define ZK_SORT_DISPATCH(c, CALL)                   \
-    switch ((c)->sort_variant) {                    \
+#define ZK_SORT_DISPATCH(c, CALL) ZK_SORT_DISPATCH_V((c)->sort_variant, CALL)
+#define ZK_SORT_DISPATCH_V(v, CALL)                 \
+    switch (v) {                                    \
         case 1: return Sorter<V1>::CALL;            \
         case 2: return Sorter<V2>::CALL;            \
         case 3: return Sorter<V3>::CALL;            \
@@ -538,7 +539,7 @@ int sort_keys(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** re
 int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, u64** rk, u32** rv) {
     *rk = keys; *rv = vals;
     if (n == 0) return ZK_OK;
-    ZK_SORT_DISPATCH(c, sort_pairs(c, keys, alt, vals, valt, n, key_bits, rk, rv));
+    ZK_SORT_DISPATCH_V(c->pairs_variant, sort_pairs(c, keys, alt, vals, valt, n, key_bits, rk, rv));
 }
 
 int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,

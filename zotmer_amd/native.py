@@ -71,6 +71,7 @@ SIGNATURES = {
     "zk_merge_n": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _pu64, _vp, _vp, _u64, _pu64, _pu64]),
     "zk_project_dedupe": (_i, [_vp, _vp, _u64, _i, _vp, _u64, _pu64]),
     "zk_split": (_i, [_vp, _vp, _u64, _vp, _u64, _pu64]),
+    "zk_lower_bound": (_i, [_vp, _vp, _u64, _pu64, _u32, _pu64]),
     "zk_trim": (_i, [_vp, _vp, _vp, _i, _u64, _u64, _u64, _vp, _vp, _u64, _pu64]),
     "zk_codec64_encode": (_i, [_vp, _u64, _i, _vp, _u64, _pu64]),
     "zk_codec64_count": (_i, [_vp, _u64, _pu64]),
@@ -197,9 +198,11 @@ class Context:
     PROF_TAGS = {"hist_stream": 1, "hist_array": 2, "pass_stream": 3, "pass_keys": 4, "pass_pairs": 5, "rle": 6,
                  "union_sum": 7, "select": 8, "mirror": 9, "intersect": 10, "count_hist": 11}
 
-    def tune(self, sort_variant=None):
+    def tune(self, sort_variant=None, pairs_variant=None):
         if sort_variant is not None:
             self._check(self.lib.zk_tune(self.h, 1, int(sort_variant)))
+        if pairs_variant is not None:
+            self._check(self.lib.zk_tune(self.h, 2, int(pairs_variant)))
 
     def profile(self, enable=True):
         self._check(self.lib.zk_profile(self.h, int(enable)))
@@ -325,6 +328,13 @@ class Context:
         abc = (C.c_uint64 * 3)()
         self._check(self.lib.zk_split(self.h, x.ptr, x.n, y.ptr, y.n, abc))
         return tuple(int(v) for v in abc)
+
+    def lower_bound(self, sorted_keys, queries):
+        q = np.ascontiguousarray(queries, dtype=np.uint64)
+        pos = np.zeros(len(q), dtype=np.uint64)
+        self._check(self.lib.zk_lower_bound(self.h, sorted_keys.ptr, sorted_keys.n, q.ctypes.data_as(_pu64), len(q),
+                                            pos.ctypes.data_as(_pu64)))
+        return [int(p) for p in pos]
 
     def trim(self, kmers, counts, lo, hi=0):
         bits = counts.dtype.itemsize * 8

@@ -1,0 +1,130 @@
+"""
+Multi-GPU exchange step: one process per GPU, `torch.distributed` with
+the "nccl" backend (= RCCL over xGMI on ROCm).
+
+kmerize shards READS: every rank counts its own reads with no communication at all.  The per-rank
+tables then meet in ONE exchange: the k-mer value space [0, 4**K) is cut into `world` contiguous
+ranges, each rank sends range r of its sorted table to rank r with a single all-to-all-v (a sorted
+table is already partitioned: the cut points are binary searches, no scatter), and every rank
+union-sums the `world` sorted pieces it receives.  Rank r then owns the r-th contiguous range of the
+global table, so the global sorted set is the concatenation of the ranks' tables in rank order.
+xGMI is a full mesh: an all-to-all is one hop per peer and per-link bound.
+
+`dist` (a, b, c) counts are additive over any partition of the key space: partition both sets with the
+same splitters, zk_split locally, all-reduce three integers (`split_counts`).
+
+The arithmetic on the data path is injected (`ops`), so the protocol -- split sizes, the two
+all-to-all rounds, merge order, the checksum reduction -- runs unchanged under the "gloo" backend on
+CPU tensors in the tests.
+"""
+import numpy as np
+import torch
+
+
+def splitters(K, world):
+    """world-1 ascending cut points of [0, 4**K): range r is [cut[r-1], cut[r])."""
+    space = 1 << (2 * K)
+    return [(space * r) // world for r in range(1, world)]
+
+
+class GpuOps:
+    """Data-path operations on torch CUDA tensors through libzotk (the tensors only carry bytes:
+    uint64 k-mers travel as int64, uint32 counts as int32)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        from zotmer_amd import native
+        self._borrow = native.DeviceArray.borrow
+
+    def empty(self, n, dtype):
+        return torch.empty(max(int(n), 1), dtype=dtype, device="cuda")
+
+    def k_array(self, t, n, off=0):
+        return self._borrow(self.ctx, t.data_ptr() + 8 * off, np.uint64, n, keep=t)
+
+    def c_array(self, t, n, off=0):
+        return self._borrow(self.ctx, t.data_ptr() + 4 * off, np.uint32, n, keep=t)
+
+    def lower_bound(self, keys_t, n, cuts):
+        return self.ctx.lower_bound(self.k_array(keys_t, n), cuts)
+
+    def before_comm(self):
+        self.ctx.sync()                 # our kernels run on the ctx's own stream
+
+    def after_comm(self):
+        torch.cuda.synchronize()
+
+    def merge_segments(self, keys_t, counts_t, segs):
+        """Union-sum the sorted segments [(offset, length)] of the receive buffers pairwise."""
+        parts = [(self.k_array(keys_t, n, o), self.c_array(counts_t, n, o)) for o, n in segs if n]
+        if not parts:
+            return self.k_array(keys_t, 0), self.c_array(counts_t, 0)
+        while len(parts) > 1:
+            nxt = []
+            for i in range(0, len(parts) - 1, 2):
+                nxt.append(self.ctx.union_sum(parts[i][0], parts[i][1], parts[i + 1][0], parts[i + 1][1]))
+            if len(parts) & 1:
+                nxt.append(parts[-1])
+            parts = nxt
+        return parts[0]
+
+    def checksum(self, k, c):
+        return self.ctx.checksum(k, c)
+
+
+class RangeExchange:
+    def __init__(self, ctx, dist, K, ops=None):
+        self.dist, self.K = dist, K
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.ops = ops if ops is not None else GpuOps(ctx)
+        self.cuts = splitters(K, self.world)
+
+    def exchange(self, keys_t, counts_t, n):
+        """keys_t (int64) / counts_t (int32): this rank's sorted table in its first n entries.
+        Returns (recv keys, recv counts, [(offset, length) per source rank])."""
+        ops, dist, W = self.ops, self.dist, self.world
+        pos = [0] + ops.lower_bound(keys_t, n, self.cuts) + [n]
+        send = [pos[r + 1] - pos[r] for r in range(W)]
+        ops.before_comm()
+        s = torch.tensor(send, dtype=torch.int64, device=keys_t.device)
+        r = torch.empty(W, dtype=torch.int64, device=keys_t.device)
+        dist.all_to_all_single(r, s)
+        recv = [int(v) for v in r.tolist()]
+        total = sum(recv)
+        rk = ops.empty(total, torch.int64)
+        rc = ops.empty(total, torch.int32)
+        dist.all_to_all_single(rk[:total], keys_t[:n], recv, send)
+        dist.all_to_all_single(rc[:total], counts_t[:n], recv, send)
+        ops.after_comm()
+        segs, off = [], 0
+        for m in recv:
+            segs.append((off, m))
+            off += m
+        return rk, rc, segs
+
+    def exchange_and_merge(self, keys_t, counts_t, n):
+        rk, rc, segs = self.exchange(keys_t, counts_t, n)
+        return self.ops.merge_segments(rk, rc, segs)
+
+    def verify_global(self, k, c, local_stream_sums):
+        """Sum over ranks of the merged tables' checksums == sum over ranks of the streams' checksums
+        (each a triple mod 2**64; carried as 32-bit halves so the reduction cannot overflow)."""
+        got = self.ops.checksum(k, c)
+
+        def halves(t):
+            return [v & 0xFFFFFFFF for v in t] + [v >> 32 for v in t]
+        dev = "cuda" if torch.cuda.is_available() and self.dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor(halves(got) + halves(local_stream_sums), dtype=torch.int64, device=dev)
+        self.dist.all_reduce(t)
+        v = [int(x) for x in t.tolist()]
+
+        def join(lo, hi):
+            return [(l + (h << 32)) & 0xFFFFFFFFFFFFFFFF for l, h in zip(lo, hi)]
+        return join(v[0:3], v[3:6]) == join(v[6:9], v[9:12])
+
+    def split_counts(self, abc_local):
+        """dist: all-reduce the (a, b, c) of the rank's key range."""
+        dev = "cuda" if torch.cuda.is_available() and self.dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor(list(abc_local), dtype=torch.int64, device=dev)
+        self.dist.all_reduce(t)
+        return tuple(int(x) for x in t.tolist())
