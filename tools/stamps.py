@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase time of pass_kernel from in-kernel s_memtime stamps.
+Build first with:  make -C zotmer_amd/csrc clean && make -C zotmer_amd/csrc CXXFLAGS_EXTRA=-DZK_STAMPS
+Shares, not absolute times, are what to read (the stamped build is slower)."""
+import sys, os, json
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from zotmer_amd import native
+
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1 << 28
+variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+tile = {0: 8192, 3: 8192, 4: 8192, 5: 8192, 1: 4096, 6: 4096, 2: 16384, 7: 16384}[variant]
+ctx = native.Context(0)
+ctx.tune(sort_variant=variant)
+rng = np.random.default_rng(1)
+keys = ctx.upload(rng.integers(0, 1 << 50, size=n, dtype=np.uint64))
+tiles = (n + tile - 1) // tile
+dbg = ctx.empty(tiles * 9, np.uint64)
+ctx.sort_keys(keys, 50)           # warm
+keys = ctx.upload(rng.integers(0, 1 << 50, size=n, dtype=np.uint64))
+ctx._check(ctx.lib.zk_debug_buffer(ctx.h, dbg.ptr))
+ctx.sort_keys(keys, 50)           # the stamps of the LAST pass remain
+ctx._check(ctx.lib.zk_debug_buffer(ctx.h, None))
+raw = dbg.to_host()
+s = raw[:tiles * 8].reshape(tiles, 8).astype(np.int64)
+ss = raw[tiles * 8:]
+steps = (ss >> np.uint64(32)).astype(np.int64)[1:]
+spins = (ss & np.uint64(0xFFFFFFFF)).astype(np.int64)[1:]
+d = np.diff(s, axis=1)
+names = ["load wait", "rank (wave 0)", "barrier after rank", "digit scan", "look-back (thread 0)", "barrier after look-back", "regroup + store"]
+tot = (s[:, 7] - s[:, 0])
+print(json.dumps({"steps_hist": np.bincount(np.minimum(steps, 12)).tolist(), "spins_mean": float(spins.mean()), "spins_p50_p90_p99": [float(np.percentile(spins, q)) for q in (50, 90, 99)],
+                  "frac_tiles_with_spin": float((spins > 0).mean()),
+                  "tiles": int(tiles), "median_total_ticks": float(np.median(tot)),
+                  "phases_median_ticks": {nm: float(np.median(d[:, i])) for i, nm in enumerate(names)},
+                  "phases_mean_share": {nm: float(d[:, i].sum() / tot.sum()) for i, nm in enumerate(names)}}, indent=1))

@@ -216,6 +216,13 @@ int zk_tune(zk_ctx* c, int what, int value) {
     return fail(c, ZK_EINVAL, "unknown tuning knob %d", what);
 }
 
+// diagnostic builds only (-DZK_STAMPS): where pass_kernel writes its per-tile time stamps
+int zk_debug_buffer(zk_ctx* c, void* d_buf) {
+    if (!c) return ZK_EINVAL;
+    c->dbg = (u64*)d_buf;
+    return ZK_OK;
+}
+
 int zk_profile(zk_ctx* c, int enable) {
     if (!c) return ZK_EINVAL;
     ZK_HIP(c, hipStreamSynchronize(c->stream));

@@ -14,7 +14,7 @@ struct zk_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cus = 256;
-    int sort_variant = 6;      // radix-sort geometry for key arrays (zk_tune); 6 = 512 threads x 16 keys, 9-bit digits
+    int sort_variant = 3;      // radix-sort geometry for key arrays (zk_tune); 3 = 512 threads x 16 keys, 9-bit digits
     int pairs_variant = 0;     // ... for (key, u32) pairs; 0 = 512 x 16, 8-bit digits (fewer registers with the payload)
 
     // workspace arena: a bump allocator reset at the start of every API call
@@ -39,6 +39,7 @@ struct zk_ctx {
     u64* h_scalars = nullptr;  // pinned mirror
 
     std::string last_error;
+    u64* dbg = nullptr;        // diagnostic stamp buffer (zk_debug_buffer), normally null
 
     // optional per-launch timing with HIP events on this stream (zk_profile_*)
     struct ProfRec { int tag; uint64_t bytes; hipEvent_t a, b; };

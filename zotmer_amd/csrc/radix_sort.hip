@@ -32,9 +32,11 @@ constexpr int MAX_RADIX = 1024;
 
 enum { SRC_ARRAY = 0, SRC_STREAM = 1 };
 
-template <int BLOCK_, int ITEMS_, int RBITS_>
+// LB_: 0 = publish the tile's digit counts after the ranking; 4 = count with LDS atomics first,
+//          publish, then rank (the ranking overlaps the successors' look-back).
+template <int BLOCK_, int ITEMS_, int RBITS_, int LB_ = 0>
 struct Cfg {
-    static constexpr int BLOCK = BLOCK_, ITEMS = ITEMS_, RBITS = RBITS_;
+    static constexpr int BLOCK = BLOCK_, ITEMS = ITEMS_, RBITS = RBITS_, LB = LB_;
     static constexpr int TILE = BLOCK * ITEMS, RADIX = 1 << RBITS, NW = BLOCK / 64;
     static constexpr int DPT = (RADIX + BLOCK - 1) / BLOCK;   // digits per thread in the per-digit steps
     static_assert(ITEMS % 2 == 0 && 2 * ITEMS < 256, "ITEMS");
@@ -86,7 +88,15 @@ struct SortArgs {
     u32 ticket_base;
     u32 epoch;
     u32* err;
+    u64* dbg;           // diagnostic build (-DZK_STAMPS) only: 8 time stamps per tile
+    u64* dbg2;          // ... steps << 32 | spins of thread 0's look-back chain, per tile
 };
+
+#ifdef ZK_STAMPS
+#define ZK_STAMP(k) do { if (a.dbg && threadIdx.x == 0) a.dbg[(u64)tile * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ZK_STAMP(k) do { } while (0)
+#endif
 
 // Generate this thread's ITEMS keys of tile `tile` in wave-striped order.
 //   array : key i of lane l of wave w is element  tile*TILE + w*64*ITEMS + i*64 + l
@@ -246,12 +256,31 @@ struct PassSmem {
         TileImage<C::TILE> img;
     };
     u16 cnt[C::NW][C::RADIX];
+    u32 hist[C::LB == 4 ? C::RADIX : 1];   // early tile histogram (LB 4 only)
     u32 digit_off[C::RADIX];
     u64 gbase[C::RADIX];
     u32 wsum[C::NW];
     u32 ticket;
     u32 total_live;
 };
+
+// Walk back over the predecessors of `tile` for one digit: add PARTIAL counts until an INCLUSIVE
+// prefix is met.  `q` points at the word of tile-1.  A word that is not published yet is polled again.
+__device__ __forceinline__ u64 lookback_walk(const u64* q, u32 tile, int radix, u32 epoch, u32* err) {
+    u64 excl = 0;
+    for (u32 t = tile; t > 0; t--, q -= radix) {
+        u64 w = ld_agent(q);
+        int spins = 0;
+        while (st_state(w, epoch) == 0) {
+            if (++spins > ZK_SPIN_LIMIT) { atomicOr(err, ZK_DERR_SPIN_TIMEOUT); break; }
+            __builtin_amdgcn_s_sleep(1);
+            w = ld_agent(q);
+        }
+        excl += w & ZK_ST_VALUE_MASK;
+        if (st_state(w, epoch) != ZK_ST_PARTIAL) break;   // INCLUSIVE (or gave up)
+    }
+    return excl;
+}
 
 template <class C, int SRC, bool PAIRS>
 __global__ __launch_bounds__(C::BLOCK) void pass_kernel(SortArgs a) {
@@ -260,43 +289,87 @@ __global__ __launch_bounds__(C::BLOCK) void pass_kernel(SortArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     const u32 tile = take_ticket(a.ticket, &sm.ticket) - a.ticket_base;
+    ZK_STAMP(0);
 
     u64 key[ITEMS];
     u32 val[ITEMS];
     u32 unused = 0;
     const u32 live = load_tile<C, SRC, PAIRS, false>(a, tile, &sm.img, key, val, unused);
+    const u32 dmask = (1u << a.bits) - 1u;
 
-    // ---- rank inside the wave ------------------------------------------------------------
     u16* mycnt = sm.cnt[wave];
     for (int d = lane; d < RADIX; d += 64) mycnt[d] = 0;
+    if (C::LB == 4)
+        for (int d = tid; d < RADIX; d += BLOCK) sm.hist[d] = 0;
     __syncthreads();
-    const u32 dmask = (1u << a.bits) - 1u;
+#ifdef ZK_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ZK_STAMP(1);     // keys have arrived
+#endif
+
+    // thread t owns digits t*DPT .. t*DPT+DPT-1 in the per-digit steps
+    u32 tcount[DPT];
+    u32 dig_excl = 0;
+
+    if (C::LB == 4) {
+        // ---- early publish ----------------------------------------------------------------------
+        // Measured with in-kernel stamps: with the publish after the ranking, a tile spent 40 % of
+        // its life in the look-back, almost all of it waiting for predecessors that were still
+        // ranking (workgroups reach that point with microseconds of jitter).  The digit COUNTS need
+        // no ranking, only a histogram (LDS atomics, a fraction of the ranking's cost).  So: count,
+        // publish, rank -- the ranking of every tile now overlaps its successors' waiting.
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++)
+            if ((live >> i) & 1u) atomicAdd(&sm.hist[(u32)(key[i] >> a.shift) & dmask], 1u);
+        __syncthreads();
+        u32 tsum = 0;
+#pragma unroll
+        for (int j = 0; j < DPT; j++) {
+            const int d = tid * DPT + j;
+            tcount[j] = (d < RADIX) ? sm.hist[d] : 0u;
+            tsum += tcount[j];
+            if (d < RADIX)
+                st_agent(a.status + (u64)tile * RADIX + d, st_pack(tile == 0 ? ZK_ST_INCLUSIVE : ZK_ST_PARTIAL, a.epoch, tcount[j]));
+        }
+        const u32 inc = wave_incl_scan_u32(tsum);
+        if (lane == 63) sm.wsum[wave] = inc;
+        __syncthreads();
+        u32 woff = 0;
+        for (int w = 0; w < wave; w++) woff += sm.wsum[w];
+        dig_excl = woff + inc - tsum;
+        if (tid == BLOCK - 1) sm.total_live = woff + inc;
+    }
+
+    // ---- rank inside the wave ------------------------------------------------------------
     u32 rank[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const bool lv = (live >> i) & 1u;
         const u32 d = (u32)(key[i] >> a.shift) & dmask;
-        u64 peers = __ballot(lv);
+        // match-any over the digit bits: peers = live lanes of the wave holding the same digit.
+        // All RBITS bits are always tested (bits above a.bits are zero in every lane, so they
+        // change nothing) -- no data-dependent or pass-dependent branch in the loop.
+        const u64 lm = __ballot(lv);
+        u32 plo = (u32)lm, phi = (u32)(lm >> 32);
 #pragma unroll
         for (int b = 0; b < C::RBITS; b++) {
-            if (b < a.bits) {
-                const bool bit = (d >> b) & 1u;
-                const u64 m = __ballot(bit);
-                peers &= bit ? m : ~m;
-            }
+            const u32 B = (u32)__builtin_amdgcn_sbfe((int)d, b, 1);   // 0 or ~0
+            const u64 m = __ballot(B != 0);
+            plo &= ~((u32)m ^ B);
+            phi &= ~((u32)(m >> 32) ^ B);
         }
-        const u32 below = popc_below(peers);
-        const u32 npeer = (u32)__popcll(peers);
+        const u32 below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+        const u32 npeer = (u32)__popc(plo) + (u32)__popc(phi);
         const u32 pre = lv ? (u32)mycnt[d] : 0u;
         rank[i] = pre + below;
         if (lv && below == npeer - 1) mycnt[d] = (u16)(pre + npeer);   // highest peer lane updates
     }
+    ZK_STAMP(2);         // this wave ranked
     __syncthreads();
+    ZK_STAMP(3);         // every wave ranked
 
     // ---- per digit: exclusive scan over the waves, tile total ---------------------------------
-    // thread t owns digits t*DPT .. t*DPT+DPT-1
-    u32 tcount[DPT];
-    u32 tsum = 0;
+    u32 tsum2 = 0;
 #pragma unroll
     for (int j = 0; j < DPT; j++) {
         const int d = tid * DPT + j;
@@ -309,19 +382,22 @@ __global__ __launch_bounds__(C::BLOCK) void pass_kernel(SortArgs a) {
                 acc += t;
             }
         }
-        tcount[j] = acc;
-        tsum += acc;
+        if (C::LB != 4) tcount[j] = acc;
+        tsum2 += acc;
     }
-    // exclusive scan over the digits
-    const u32 inc = wave_incl_scan_u32(tsum);
-    if (lane == 63) sm.wsum[wave] = inc;
-    __syncthreads();
-    u32 woff = 0;
-    for (int w = 0; w < wave; w++) woff += sm.wsum[w];
-    u32 dig_excl = woff + inc - tsum;
-    if (tid == BLOCK - 1) sm.total_live = woff + inc;
+    if (C::LB != 4) {
+        // exclusive scan over the digits
+        const u32 inc = wave_incl_scan_u32(tsum2);
+        if (lane == 63) sm.wsum[wave] = inc;
+        __syncthreads();
+        u32 woff = 0;
+        for (int w = 0; w < wave; w++) woff += sm.wsum[w];
+        dig_excl = woff + inc - tsum2;
+        if (tid == BLOCK - 1) sm.total_live = woff + inc;
+    }
 
     // ---- decoupled look-back, one chain per digit ----------------------------------------------
+    ZK_STAMP(4);
 #pragma unroll
     for (int j = 0; j < DPT; j++) {
         const int d = tid * DPT + j;
@@ -329,21 +405,19 @@ __global__ __launch_bounds__(C::BLOCK) void pass_kernel(SortArgs a) {
             u64* st = a.status + (u64)tile * RADIX + d;
             u64 excl = 0;
             if (tile == 0) {
-                st_agent(st, st_pack(ZK_ST_INCLUSIVE, a.epoch, tcount[j]));
+                if (C::LB != 4) st_agent(st, st_pack(ZK_ST_INCLUSIVE, a.epoch, tcount[j]));
             } else {
-                st_agent(st, st_pack(ZK_ST_PARTIAL, a.epoch, tcount[j]));
-                const u64* q = st - RADIX;
-                for (u32 t = tile; t > 0; t--, q -= RADIX) {
-                    u64 w = ld_agent(q);
-                    int spins = 0;
-                    while (st_state(w, a.epoch) == 0) {
-                        if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT); break; }
-                        __builtin_amdgcn_s_sleep(1);
-                        w = ld_agent(q);
-                    }
-                    excl += w & ZK_ST_VALUE_MASK;
-                    if (st_state(w, a.epoch) != ZK_ST_PARTIAL) break;   // INCLUSIVE (or gave up)
+                if (C::LB != 4) st_agent(st, st_pack(ZK_ST_PARTIAL, a.epoch, tcount[j]));
+#ifdef ZK_NO_LOOKBACK   /* timing experiment only: results are wrong */
+                {   // stay inside the digit's bin so every store is in range
+                    const u64 lo = a.ghist[d], hi = (d + 1 < RADIX) ? a.ghist[d + 1] : a.n;
+                    const u64 room = (hi - lo >= tcount[j]) ? (hi - lo - tcount[j]) : 0;
+                    excl = (u64)tile * tcount[j];
+                    if (excl > room) excl = room;
                 }
+#else
+                excl = lookback_walk(st - RADIX, tile, RADIX, a.epoch, a.err);
+#endif
                 st_agent(st, st_pack(ZK_ST_INCLUSIVE, a.epoch, excl + tcount[j]));
             }
             sm.digit_off[d] = dig_excl;
@@ -351,7 +425,9 @@ __global__ __launch_bounds__(C::BLOCK) void pass_kernel(SortArgs a) {
             dig_excl += tcount[j];
         }
     }
+    ZK_STAMP(5);         // this thread's look-back chain done
     __syncthreads();
+    ZK_STAMP(6);         // every chain done
 
     // ---- regroup the tile by digit in LDS ---------------------------------------------------
     u32 lpos[ITEMS];
@@ -375,6 +451,10 @@ __global__ __launch_bounds__(C::BLOCK) void pass_kernel(SortArgs a) {
             a.kout[gpos[i]] = k;
         }
     }
+#ifdef ZK_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ZK_STAMP(7);         // keys stored
+#endif
     if (PAIRS) {
         __syncthreads();
         u32* exv = reinterpret_cast<u32*>(sm.exch);
@@ -409,6 +489,8 @@ struct Sorter {
         a.status = c->status;
         a.ticket = c->d_ticket;
         a.err = c->d_err;
+        a.dbg = c->dbg;
+        a.dbg2 = c->dbg ? c->dbg + 8ull * tiles : nullptr;
         prof_begin(c, SRC == SRC_STREAM ? ZK_PROF_PASS_STREAM : (PAIRS ? ZK_PROF_PASS_PAIRS : ZK_PROF_PASS_KEYS),
                    SRC == SRC_STREAM ? a.n_bytes + 8 * a.n : (PAIRS ? 24 : 16) * a.n);
         hipLaunchKernelGGL((pass_kernel<C, SRC, PAIRS>), dim3(tiles), dim3(C::BLOCK), 0, c->stream, a);
@@ -510,14 +592,15 @@ struct Sorter {
     }
 };
 
-// the instantiated geometries; index = zk_tune(ZK_TUNE_SORT_VARIANT)
-typedef Cfg<512, 16, 8> V0;
-typedef Cfg<256, 16, 8> V1;
-typedef Cfg<256, 8, 8> V2;
-typedef Cfg<1024, 16, 8> V3;
-typedef Cfg<512, 8, 8> V4;
-typedef Cfg<1024, 8, 10> V5;
-typedef Cfg<512, 16, 9> V6;
+// the instantiated geometries; index = zk_tune(ZK_TUNE_SORT_VARIANT / ZK_TUNE_PAIRS_VARIANT)
+typedef Cfg<512, 16, 8, 0> V0;
+typedef Cfg<256, 16, 8, 0> V1;
+typedef Cfg<1024, 16, 8, 0> V2;
+typedef Cfg<512, 16, 9, 0> V3;
+typedef Cfg<512, 16, 8, 4> V4;
+typedef Cfg<512, 16, 9, 4> V5;
+typedef Cfg<256, 16, 8, 4> V6;
+typedef Cfg<1024, 16, 8, 4> V7;
 #define ZK_SORT_DISPATCH(c, CALL) ZK_SORT_DISPATCH_V((c)->sort_variant, CALL)
 #define ZK_SORT_DISPATCH_V(v, CALL)                 \
     switch (v) {                                    \
@@ -527,6 +610,7 @@ typedef Cfg<512, 16, 9> V6;
         case 4: return Sorter<V4>::CALL;            \
         case 5: return Sorter<V5>::CALL;            \
         case 6: return Sorter<V6>::CALL;            \
+        case 7: return Sorter<V7>::CALL;            \
         default: return Sorter<V0>::CALL;           \
     }
 

@@ -54,6 +54,7 @@ SIGNATURES = {
     "zk_download": (_i, [_vp, _vp, _vp, _u64]),
     "zk_copy": (_i, [_vp, _vp, _vp, _u64]),
     "zk_tune": (_i, [_vp, _i, _i]),
+    "zk_debug_buffer": (_i, [_vp, _vp]),
     "zk_profile": (_i, [_vp, _i]),
     "zk_profile_read": (_i, [_vp, _i, _pu64, C.POINTER(C.c_double), _pu64]),
     "zk_pack_reads": (_i, [_vp, _vp, _vp, _u64, _vp]),
