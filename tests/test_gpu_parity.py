@@ -123,8 +123,9 @@ def test_rle(ctx, in_place):
     rng = np.random.default_rng(5)
     vals = np.sort(rng.choice(np.arange(1, 10 ** 7, dtype=np.uint64), size=30000, replace=False))
     reps = rng.integers(1, 6, size=len(vals))
-    reps[100] = 7000            # a run across several 2048-element tiles
-    reps[101] = 2048
+    reps[100] = 30000           # a run across several 8192-element tiles
+    reps[101] = 8192
+    reps[5000] = 8193
     reps[-1] = 5000             # ... and one that ends the array
     x = np.repeat(vals, reps)
     u, c = ctx.rle(ctx.upload(x), in_place=in_place)

@@ -37,21 +37,24 @@ struct SelState {
     u32 tiles;
 };
 
-struct SelSmem {
-    u32 wtot[SEL_NW];
+template <int NW>
+struct SelSmemT {
+    u32 wtot[NW];
     u64 tile_excl;
     u32 ticket;
 };
+typedef SelSmemT<SEL_NW> SelSmem;
 
 // Returns the global output offset of this WAVE's first kept element; *tile_total gets the
 // tile's number of kept elements.  All threads of the workgroup must call it.
-__device__ __forceinline__ u64 select_wave_base(SelSmem& sm, const SelState& st, u32 tile, u32 wave_total, u32* tile_total) {
+template <int NW>
+__device__ __forceinline__ u64 select_wave_base(SelSmemT<NW>& sm, const SelState& st, u32 tile, u32 wave_total, u32* tile_total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) sm.wtot[wave] = wave_total;
     __syncthreads();
     u32 wex = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < SEL_NW; w++) {
+    for (int w = 0; w < NW; w++) {
         if (w < wave) wex += sm.wtot[w];
         tot += sm.wtot[w];
     }
@@ -72,34 +75,45 @@ __device__ __forceinline__ u64 select_wave_base(SelSmem& sm, const SelState& st,
 // A run that crosses a tile boundary is finished by rle_fixup_kernel: every tile records how
 // many of its leading elements continue the previous tile's last run.
 // ---------------------------------------------------------------------------------------
+constexpr int RLE_BLOCK = 512;
+constexpr int RLE_ITEMS = 16;
+constexpr int RLE_TILE = RLE_BLOCK * RLE_ITEMS;
+constexpr int RLE_NW = RLE_BLOCK / 64;
+constexpr u32 RLE_NONE = 0xFFFFFFFFu;
+
 struct RleSmem {
-    SelSmem sel;
-    u64 hkey[SEL_TILE];
-    u32 hidx[SEL_TILE];
+    SelSmemT<RLE_NW> sel;
+    u32 wfirst[RLE_NW];     // tile-relative position of each wave's first head, or RLE_NONE
 };
 
 // `uniq` may alias `keys` (in-place): a tile learns its output offset only after every earlier
 // tile has loaded its inputs, outputs never land beyond the tile's own input range, and the one
 // neighbour element a later tile may still read can only be overwritten with its own value.
-__global__ __launch_bounds__(SEL_BLOCK) void rle_kernel(const u64* keys, u64 n, u64* uniq,
+//
+// Everything stays in registers: the head flags of a row are one ballot, a head's run length is
+// the distance to the next set bit (same row, a later row of the wave, a later wave via LDS, or
+// the end of the tile), its output slot a popcount.  8192 keys per tile keep the tile rate -- and
+// with it the length of the look-back chains -- low.
+__global__ __launch_bounds__(RLE_BLOCK) void rle_kernel(const u64* keys, u64 n, u64* uniq,
                                                         u32* __restrict__ counts, u64 cap, u32* __restrict__ lead,
                                                         SelState st) {
     __shared__ RleSmem sm;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u32 tile = take_ticket(st.ticket, &sm.sel.ticket) - st.ticket_base;
-    const u64 tile_base = (u64)tile * SEL_TILE;
-    const u64 base = tile_base + (u64)wave * (64 * SEL_ITEMS);
+    const u64 tile_base = (u64)tile * RLE_TILE;
+    const u32 wave_rel = (u32)wave * (64 * RLE_ITEMS);
+    const u64 base = tile_base + wave_rel;
 
-    u64 k[SEL_ITEMS];
-    u64 hm[SEL_ITEMS];
+    u64 k[RLE_ITEMS];
+    u64 hm[RLE_ITEMS];
     u32 wave_total = 0;
 #pragma unroll
-    for (int i = 0; i < SEL_ITEMS; i++) {
+    for (int i = 0; i < RLE_ITEMS; i++) {
         const u64 idx = base + (u64)i * 64 + lane;
         k[i] = (idx < n) ? keys[idx] : 0ull;
     }
 #pragma unroll
-    for (int i = 0; i < SEL_ITEMS; i++) {
+    for (int i = 0; i < RLE_ITEMS; i++) {
         const u64 idx = base + (u64)i * 64 + lane;
         u64 prev = __shfl_up(k[i], 1, 64);
         if (i > 0) {
@@ -112,34 +126,49 @@ __global__ __launch_bounds__(SEL_BLOCK) void rle_kernel(const u64* keys, u64 n, 
         hm[i] = __ballot(head);
         wave_total += (u32)__popcll(hm[i]);
     }
-    u32 tile_total;
-    const u64 wbase = select_wave_base(sm.sel, st, tile, wave_total, &tile_total);
-    const u64 tile_excl = sm.sel.tile_excl;
-    // stage (key, tile-relative index) of every head in output order
-    u32 row_off = (u32)(wbase - tile_excl);
+    // wave-relative position of the first head after row i, and of the wave's first head
+    u32 nh[RLE_ITEMS];
+    u32 run = RLE_NONE;
 #pragma unroll
-    for (int i = 0; i < SEL_ITEMS; i++) {
-        if ((hm[i] >> lane) & 1ull) {
-            const u32 q = row_off + popc_below(hm[i]);
-            sm.hkey[q] = k[i];
-            sm.hidx[q] = (u32)(wave * (64 * SEL_ITEMS) + i * 64 + lane);
-        }
-        row_off += (u32)__popcll(hm[i]);
+    for (int i = RLE_ITEMS - 1; i >= 0; i--) {
+        nh[i] = run;
+        if (hm[i]) run = (u32)(i * 64) + (u32)__builtin_ctzll(hm[i]);
     }
-    __syncthreads();
+    if (lane == 0) sm.wfirst[wave] = (run == RLE_NONE) ? RLE_NONE : wave_rel + run;
+
+    u32 tile_total;
+    const u64 wbase = select_wave_base(sm.sel, st, tile, wave_total, &tile_total);   // barriers inside
     const u64 rem = n - tile_base;
-    const u32 tile_len = rem < (u64)SEL_TILE ? (u32)rem : (u32)SEL_TILE;
-    for (u32 q = threadIdx.x; q < tile_total; q += SEL_BLOCK) {
-        const u32 end = (q + 1 < tile_total) ? sm.hidx[q + 1] : tile_len;
-        const u64 pos = tile_excl + q;
-        if (pos < cap) {
-            uniq[pos] = sm.hkey[q];
-            counts[pos] = end - sm.hidx[q];
+    const u32 tile_len = rem < (u64)RLE_TILE ? (u32)rem : (u32)RLE_TILE;
+    u32 next_wave = tile_len;      // first head in a later wave of the tile, else the tile's end
+#pragma unroll
+    for (int w = RLE_NW - 1; w >= 0; w--)
+        if (w > wave && sm.wfirst[w] != RLE_NONE) next_wave = sm.wfirst[w];
+
+    u64 q = wbase;
+#pragma unroll
+    for (int i = 0; i < RLE_ITEMS; i++) {
+        if ((hm[i] >> lane) & 1ull) {
+            const u64 above = (hm[i] >> lane) >> 1;
+            const u32 me = wave_rel + (u32)(i * 64 + lane);
+            u32 nxt;
+            if (above) nxt = me + 1 + (u32)__builtin_ctzll(above);
+            else nxt = (nh[i] != RLE_NONE) ? wave_rel + nh[i] : next_wave;
+            const u64 pos = q + popc_below(hm[i]);
+            if (pos < cap) {
+                uniq[pos] = k[i];
+                counts[pos] = nxt - me;
+            }
         }
+        q += (u32)__popcll(hm[i]);
     }
     if (threadIdx.x == 0) {
-        lead[tile] = tile_total ? sm.hidx[0] : tile_len;
-        if (tile == st.tiles - 1 && tile_excl + tile_total > cap) atomicOr(st.err, ZK_DERR_CAPACITY);
+        u32 first = tile_len;
+#pragma unroll
+        for (int w = RLE_NW - 1; w >= 0; w--)
+            if (sm.wfirst[w] != RLE_NONE) first = sm.wfirst[w];
+        lead[tile] = first;
+        if (tile == st.tiles - 1 && sm.sel.tile_excl + tile_total > cap) atomicOr(st.err, ZK_DERR_CAPACITY);
     }
 }
 
@@ -160,13 +189,13 @@ int rle(zk_ctx* c, const u64* sorted, uint64_t n, u64* uniq, u32* counts, uint64
     *n_unique = 0;
     if (n == 0) return ZK_OK;
     SelState st;
-    st.tiles = (u32)div_up(n, SEL_TILE);
+    st.tiles = (u32)div_up(n, RLE_TILE);
     u32* lead;
     ZK_TRY(arena_alloc(c, sizeof(u32) * st.tiles, (void**)&lead));
     ZK_TRY(lookback_begin(c, st.tiles, st.tiles, &st.epoch, &st.ticket_base));
     st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9;
     prof_begin(c, ZK_PROF_RLE, 8 * n);
-    hipLaunchKernelGGL(rle_kernel, dim3(st.tiles), dim3(SEL_BLOCK), 0, c->stream, sorted, (u64)n, uniq, counts, (u64)cap, lead, st);
+    hipLaunchKernelGGL(rle_kernel, dim3(st.tiles), dim3(RLE_BLOCK), 0, c->stream, sorted, (u64)n, uniq, counts, (u64)cap, lead, st);
     prof_end(c);
     ZK_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(rle_fixup_kernel, dim3((u32)div_up(st.tiles, 256)), dim3(256), 0, c->stream, lead, c->status, st.tiles,
