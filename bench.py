@@ -73,18 +73,29 @@ def main():
     ap.add_argument("--verify", action="store_true", help="check the order-free checksums of the result against the stream")
     a = ap.parse_args()
 
-    import __graft_entry__ as ge
-    ge.build()
-    from zotmer_amd import native, synth
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 or os.environ.get("ZOT_FORCE_EXCHANGE") == "1":
+        # torch bundles its own HIP runtime: let it load first so that libzotk.so binds to the same
+        # copy (same SONAME) instead of dragging a second runtime into the process
+        import torch  # noqa: F401
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    from zotmer_amd import native, synth
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    # RCCL may print a version banner on stdout; the contract is ONE JSON line there, so everything
+    # but the final print goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     dist = None
-    if world > 1:
+    force_exchange = os.environ.get("ZOT_FORCE_EXCHANGE") == "1"      # rehearse the N > 1 path with one rank
+    if world > 1 or force_exchange:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
@@ -106,7 +117,7 @@ def main():
     est_unique = int(2 * (min(cfg["genome"], R * L) + R * L * cfg["sub"] * 22) * 1.25) + (1 << 20)
     cap = min(est_unique, 2 * n_bytes)
     par = None
-    if world > 1:
+    if dist is not None:
         # the exchange goes through torch.distributed, so the table lives in torch tensors that the
         # library writes through their data_ptr() (uint64 carried as int64, uint32 as int32)
         import torch
@@ -200,7 +211,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, seed)
         elif not a.no_cpu_baseline:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.destroy_process_group()
     ctx.close()

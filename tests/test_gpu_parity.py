@@ -220,6 +220,29 @@ def test_kmerize_empty_and_tiny(ctx):
             assert list(st.acgt) == want["acgt"]
 
 
+@pytest.mark.parametrize("K", [13, 25, 31, 32])
+def test_kmerize_short_sort_paths_agree(ctx, K):
+    """zk_kmerize can sort only the top ~log2(n)+3 bits and finish in the mirror stage (opt-in); the
+    full sort, the short sort and the short sort with a side list too small to hold anything (forced
+    fall-back) must give the same arrays, also on inputs built to crowd the prefix groups."""
+    rng = np.random.default_rng(K)
+    low = ["".join(rng.choice(list("AC"), size=120)) for _ in range(1500)]            # low complexity: shared prefixes
+    poly = ["A" * 60 + "".join(rng.choice(list("ACGT"), size=40)) for _ in range(1500)]
+    reads = synth.read_strings(5, 0, 2500, 150, genome=9000, sub_thr=synth.frac32(0.01), n_thr=synth.frac32(0.001)) + low + poly
+    reads += ["ACGT" * 40, "T" * 150, "TTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTA" * 3] * 50
+    want = zo.kmerize(K, reads)
+    d = ctx.upload_stream(stream_of(reads))
+    try:
+        for kw in (dict(short_sort=0), dict(short_sort=1, side_div=8), dict(short_sort=1, side_div=1), dict(short_sort=1, side_div=10 ** 9)):
+            ctx.tune(**kw)
+            k, c, st = ctx.kmerize(d, K)
+            assert np.array_equal(k.to_host(), want["kmers"]), kw
+            assert np.array_equal(c.to_host(), want["counts"]), kw
+            assert list(st.acgt) == want["acgt"]
+    finally:
+        ctx.tune(short_sort=0, side_div=8)
+
+
 @pytest.mark.parametrize("K", [4, 24, 32])
 def test_kmerize_even_K_palindromes_vs_oracle(ctx, K):
     # even K: x == rc(x) exists; the mirrored path must count such a window twice, like two emissions

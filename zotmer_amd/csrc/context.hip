@@ -125,30 +125,50 @@ int check_device_error(zk_ctx* c) {
 
 using namespace zk;
 
+static std::string g_create_error = "no context";
+
+#define ZK_CREATE_STEP(call)                                                                      \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            char b__[256];                                                                        \
+            snprintf(b__, sizeof b__, "zk_create: %s failed: %s", #call, hipGetErrorString(e__)); \
+            g_create_error = b__;                                                                 \
+            if (c) zk_destroy(c);                                                                 \
+            return nullptr;                                                                       \
+        }                                                                                         \
+    } while (0)
+
 extern "C" {
 
 zk_ctx* zk_create(int device, uint64_t workspace_bytes) {
+    zk_ctx* c = nullptr;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return nullptr;
-    if (hipSetDevice(device) != hipSuccess) return nullptr;
-    zk_ctx* c = new zk_ctx();
+    ZK_CREATE_STEP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        char b[128];
+        snprintf(b, sizeof b, "zk_create: device %d requested, %d visible", device, ndev);
+        g_create_error = b;
+        return nullptr;
+    }
+    ZK_CREATE_STEP(hipSetDevice(device));
+    c = new zk_ctx();
     c->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
-    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-    c->own_stream = ok;
-    ok = ok && hipMalloc((void**)&c->d_ticket, sizeof(u32)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&c->d_err, sizeof(u32)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&c->d_scalars, 64 * sizeof(u64)) == hipSuccess;
-    ok = ok && hipHostMalloc((void**)&c->h_scalars, 64 * sizeof(u64), hipHostMallocDefault) == hipSuccess;
-    ok = ok && hipMemset(c->d_ticket, 0, sizeof(u32)) == hipSuccess;
-    ok = ok && hipMemset(c->d_err, 0, sizeof(u32)) == hipSuccess;
-    ok = ok && hipMemset(c->d_scalars, 0, 64 * sizeof(u64)) == hipSuccess;
-    if (ok && workspace_bytes) {
-        ok = hipMalloc((void**)&c->arena, workspace_bytes) == hipSuccess;
-        if (ok) c->arena_size = workspace_bytes;
+    ZK_CREATE_STEP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    ZK_CREATE_STEP(hipMalloc((void**)&c->d_ticket, sizeof(u32)));
+    ZK_CREATE_STEP(hipMalloc((void**)&c->d_err, sizeof(u32)));
+    ZK_CREATE_STEP(hipMalloc((void**)&c->d_scalars, 64 * sizeof(u64)));
+    ZK_CREATE_STEP(hipHostMalloc((void**)&c->h_scalars, 64 * sizeof(u64), hipHostMallocDefault));
+    ZK_CREATE_STEP(hipMemset(c->d_ticket, 0, sizeof(u32)));
+    ZK_CREATE_STEP(hipMemset(c->d_err, 0, sizeof(u32)));
+    ZK_CREATE_STEP(hipMemset(c->d_scalars, 0, 64 * sizeof(u64)));
+    if (workspace_bytes) {
+        ZK_CREATE_STEP(hipMalloc((void**)&c->arena, workspace_bytes));
+        c->arena_size = workspace_bytes;
     }
-    if (!ok) { zk_destroy(c); return nullptr; }
     return c;
 }
 
@@ -168,7 +188,7 @@ void zk_destroy(zk_ctx* c) {
     delete c;
 }
 
-const char* zk_last_error(zk_ctx* c) { return c ? c->last_error.c_str() : "no context (no MI355X visible, or bad device index)"; }
+const char* zk_last_error(zk_ctx* c) { return c ? c->last_error.c_str() : g_create_error.c_str(); }
 
 int zk_set_stream(zk_ctx* c, void* hip_stream) {
     if (!c) return ZK_EINVAL;
@@ -213,6 +233,8 @@ int zk_tune(zk_ctx* c, int what, int value) {
     if (!c) return ZK_EINVAL;
     if (what == ZK_TUNE_SORT_VARIANT) { c->sort_variant = value; return ZK_OK; }
     if (what == ZK_TUNE_PAIRS_VARIANT) { c->pairs_variant = value; return ZK_OK; }
+    if (what == ZK_TUNE_SHORT_SORT) { c->short_sort = value; return ZK_OK; }
+    if (what == ZK_TUNE_SIDE_DIV) { c->side_div = value; return ZK_OK; }
     return fail(c, ZK_EINVAL, "unknown tuning knob %d", what);
 }
 

@@ -15,7 +15,10 @@ struct zk_ctx {
     bool own_stream = false;
     int num_cus = 256;
     int sort_variant = 3;      // radix-sort geometry for key arrays (zk_tune); 3 = 512 threads x 16 keys, 9-bit digits
-    int pairs_variant = 0;     // ... for (key, u32) pairs; 0 = 512 x 16, 8-bit digits (fewer registers with the payload)
+    int short_sort = 0;        // zk_kmerize: 1 = sort only the top ~log2(n)+3 bits and finish in the mirror stage (opt-in:
+                               // pays off on uncorrelated reads only)
+    int side_div = 8;          // ... side list capacity = n / side_div (tests shrink it to force the fallback)
+    int pairs_variant = 3;     // ... for (key, u32) pairs
 
     // workspace arena: a bump allocator reset at the start of every API call
     char* arena = nullptr;
@@ -84,7 +87,8 @@ int sort_workspace_bytes(uint64_t n, bool pairs, uint64_t* bytes);
 int sort_keys(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** result);
 int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, u64** rk, u32** rv);
 // sort whose first pass generates the keys from a base stream (encode.hip + radix_sort.hip)
-struct StreamSrc { const u8* stream; uint64_t n_bytes; int K; int mode; };   // mode: ZK_KEYS_*
+struct StreamSrc { const u8* stream; uint64_t n_bytes; int K; int mode; int lo_bit; };   // mode: ZK_KEYS_*; sort bits [lo_bit, 2K)
+int sort_rbits(zk_ctx* c);
 int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,
                 uint64_t acgt[4], u64** result);
 // select.hip
@@ -97,6 +101,9 @@ int encode_list(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int both, 
                 uint64_t acgt[4]);
 int capture_filter(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, const u64* baits, uint64_t n_baits, u8* out,
                    uint64_t* n_reads, uint64_t* n_kept);
+int rle_prefix(zk_ctx* c, const u64* sorted, uint64_t n, int pshift, u64* uniq, u32* counts, uint64_t cap, uint64_t* n_main,
+               u64* side_k, u32* side_c, uint64_t side_cap, uint64_t* n_side);
+int reduce_by_key(zk_ctx* c, const u64* sorted, const u32* w, uint64_t n, u64* uniq, u32* sums, uint64_t cap, uint64_t* n_out);
 int rle(zk_ctx* c, const u64* sorted, uint64_t n, u64* uniq, u32* counts, uint64_t cap, uint64_t* n_unique);
 int count_hist(zk_ctx* c, const void* counts, int count_bits, uint64_t n, uint64_t* vals, uint64_t* freq,
                uint64_t cap_bins, uint64_t* n_bins);

@@ -47,6 +47,108 @@ int widen_counts(zk_ctx* c, const u32* in, u64* out, uint64_t n) {
     return ZK_OK;
 }
 
+// (key, n) of the side list -> the pair itself and its mirror
+__global__ void side_expand_kernel(const u64* __restrict__ k, const u32* __restrict__ n, u64 m, int K, u64* __restrict__ pk,
+                                   u32* __restrict__ pv) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (u64)gridDim.x * blockDim.x) {
+        const u64 x = k[i];
+        const u32 v = n[i];
+        pk[2 * i] = x; pv[2 * i] = v;
+        pk[2 * i + 1] = revcomp(K, x); pv[2 * i + 1] = v;
+    }
+}
+
+static int ilog2_ceil(uint64_t x) { int b = 0; while ((1ull << b) < x && b < 63) b++; return b; }
+
+// The literal paths: every bit sorted, then RLE; canonical keys are mirrored afterwards.
+static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bool both, u64* buf_a, u64* buf_b, uint64_t cap_keys,
+                        u64* out_k, u32* out_c, uint64_t cap, zk_kmerize_stats* st, uint64_t* n_out) {
+    StreamSrc src{stream, n_bytes, K, both ? ZK_KEYS_BOTH : ZK_KEYS_CANONICAL, 0};
+    uint64_t n = 0;
+    u64* sorted = nullptr;
+    ZK_TRY(sort_stream(c, src, buf_a, buf_b, cap_keys, &n, st->acgt, &sorted));
+    st->n_windows = both ? n / 2 : n;
+    st->n_instances = both ? n : 2 * n;
+    *n_out = 0;
+    if (both) {
+        st->n_canonical = 0;
+        return rle(c, sorted, n, out_k, out_c, cap, n_out);
+    }
+    u64* other = (sorted == buf_a) ? buf_b : buf_a;
+    u32* cnt = (u32*)other;
+    uint64_t uc = 0;
+    ZK_TRY(rle(c, sorted, n, sorted, cnt, n, &uc));     // in place: sorted[0..uc) = distinct canonical k-mers
+    st->n_canonical = uc;
+    if (uc == 0) return ZK_OK;
+    const uint64_t a8 = (8 * uc + 255) & ~255ull, a4 = (4 * uc + 255) & ~255ull;
+    char* aux;
+    ZK_TRY(aux_require(c, 2 * a8 + 2 * a4, &aux));
+    u64* rk = (u64*)aux; u64* rk2 = (u64*)(aux + a8);
+    u32* rv = (u32*)(aux + 2 * a8); u32* rv2 = (u32*)(aux + 2 * a8 + a4);
+    prof_begin(c, ZK_PROF_MIRROR, 24 * uc);
+    hipLaunchKernelGGL(mirror_kernel, dim3(ew_grid(c, uc)), dim3(256), 0, c->stream, sorted, cnt, (u64)uc, K, rk, rv);
+    prof_end(c);
+    ZK_HIP(c, hipGetLastError());
+    u64* sk; u32* sv;
+    ZK_TRY(sort_pairs(c, rk, rk2, rv, rv2, uc, 2 * K, &sk, &sv));
+    return union_sum(c, sorted, cnt, uc, sk, sv, uc, out_k, out_c, 32, cap, n_out, nullptr);
+}
+
+// The short path: sort only the top T bits of the canonical keys (T ~ log2(n) + 3, a whole number
+// of digits), so that nearly every group of equal prefix is a single k-mer already in its final
+// place; rle_prefix_kernel writes those to the sorted main list and everything else (mixed groups,
+// groups cut by a tile edge) to a side list, which simply joins the strand-mirror pairs in the sort
+// they need anyway.  Exact for any input; the data only decides how much goes the long way.
+// Returns 1 when the side list would not fit (caller falls back to kmerize_full).
+static int kmerize_short(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int lo_bit, u64* buf_a, u64* buf_b,
+                         uint64_t cap_keys, u64* out_k, u32* out_c, uint64_t cap, zk_kmerize_stats* st, uint64_t* n_out) {
+    StreamSrc src{stream, n_bytes, K, ZK_KEYS_CANONICAL, lo_bit};
+    uint64_t n = 0;
+    u64* sorted = nullptr;
+    ZK_TRY(sort_stream(c, src, buf_a, buf_b, cap_keys, &n, st->acgt, &sorted));
+    st->n_windows = n;
+    st->n_instances = 2 * n;
+    *n_out = 0;
+    if (n == 0) return ZK_OK;
+    char* other = (char*)((sorted == buf_a) ? buf_b : buf_a);
+    u32* cnt = (u32*)other;
+    uint64_t side_cap = n / (uint64_t)(c->side_div > 0 ? c->side_div : 8) + 64;
+    const uint64_t off_k = (4 * n + 255) & ~255ull;
+    if (off_k + 12 * side_cap > 8 * cap_keys) side_cap = (8 * cap_keys - off_k) / 12;
+    u64* side_k = (u64*)(other + off_k);
+    u32* side_c = (u32*)(other + off_k + 8 * side_cap);
+    uint64_t um = 0, ns = 0;
+    ZK_TRY(rle_prefix(c, sorted, n, lo_bit, sorted, cnt, n, &um, side_k, side_c, side_cap, &ns));
+    if (ns > side_cap) return 1;
+    st->n_canonical = um + ns;
+    const uint64_t m = um + 2 * ns;
+    const uint64_t a8 = (8 * m + 255) & ~255ull, a4 = (4 * m + 255) & ~255ull;
+    char* aux;
+    ZK_TRY(aux_require(c, (ns ? 3 : 2) * (a8 + a4), &aux));
+    u64* pk = (u64*)aux; u64* pk2 = (u64*)(aux + a8);
+    u32* pv = (u32*)(aux + 2 * a8); u32* pv2 = (u32*)(aux + 2 * a8 + a4);
+    if (um) {
+        prof_begin(c, ZK_PROF_MIRROR, 24 * um);
+        hipLaunchKernelGGL(mirror_kernel, dim3(ew_grid(c, um)), dim3(256), 0, c->stream, sorted, cnt, (u64)um, K, pk, pv);
+        prof_end(c);
+        ZK_HIP(c, hipGetLastError());
+    }
+    if (ns) {
+        hipLaunchKernelGGL(side_expand_kernel, dim3(ew_grid(c, ns)), dim3(256), 0, c->stream, side_k, side_c, (u64)ns, K, pk + um, pv + um);
+        ZK_HIP(c, hipGetLastError());
+    }
+    u64* sk; u32* sv;
+    ZK_TRY(sort_pairs(c, pk, pk2, pv, pv2, m, 2 * K, &sk, &sv));
+    uint64_t mr = m;
+    if (ns) {
+        u64* rk = (u64*)(aux + 2 * a8 + 2 * a4);
+        u32* rv = (u32*)(aux + 3 * a8 + 2 * a4);
+        ZK_TRY(reduce_by_key(c, sk, sv, m, rk, rv, m, &mr));
+        sk = rk; sv = rv;
+    }
+    return union_sum(c, sorted, cnt, um, sk, sv, mr, out_k, out_c, 32, cap, n_out, nullptr);
+}
+
 int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, double p, uint64_t seed, u64* out_k, u32* out_c,
             uint64_t cap, zk_kmerize_stats* st) {
     memset(st, 0, sizeof *st);
@@ -61,37 +163,18 @@ int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, dou
     ZK_TRY(arena_alloc(c, 8 * cap_keys, (void**)&buf_a));
     ZK_TRY(arena_alloc(c, 8 * cap_keys, (void**)&buf_b));
 
-    StreamSrc src{stream, n_bytes, K, both ? ZK_KEYS_BOTH : ZK_KEYS_CANONICAL};
-    uint64_t n = 0;
-    u64* sorted = nullptr;
-    ZK_TRY(sort_stream(c, src, buf_a, buf_b, cap_keys, &n, st->acgt, &sorted));
-    st->n_windows = both ? n / 2 : n;
-    st->n_instances = both ? n : 2 * n;
     uint64_t n_out = 0;
-    if (both) {
-        ZK_TRY(rle(c, sorted, n, out_k, out_c, cap, &n_out));
-        st->n_canonical = 0;
-    } else {
-        u64* other = (sorted == buf_a) ? buf_b : buf_a;
-        u32* cnt = (u32*)other;
-        uint64_t uc = 0;
-        ZK_TRY(rle(c, sorted, n, sorted, cnt, n, &uc));     // in place: sorted[0..uc) = distinct canonical k-mers
-        st->n_canonical = uc;
-        if (uc) {
-            const uint64_t a8 = (8 * uc + 255) & ~255ull, a4 = (4 * uc + 255) & ~255ull;
-            char* aux;
-            ZK_TRY(aux_require(c, 2 * a8 + 2 * a4, &aux));
-            u64* rk = (u64*)aux; u64* rk2 = (u64*)(aux + a8);
-            u32* rv = (u32*)(aux + 2 * a8); u32* rv2 = (u32*)(aux + 2 * a8 + a4);
-            prof_begin(c, ZK_PROF_MIRROR, 24 * uc);
-            hipLaunchKernelGGL(mirror_kernel, dim3(ew_grid(c, uc)), dim3(256), 0, c->stream, sorted, cnt, (u64)uc, K, rk, rv);
-            prof_end(c);
-            ZK_HIP(c, hipGetLastError());
-            u64* sk; u32* sv;
-            ZK_TRY(sort_pairs(c, rk, rk2, rv, rv2, uc, 2 * K, &sk, &sv));
-            ZK_TRY(union_sum(c, sorted, cnt, uc, sk, sv, uc, out_k, out_c, 32, cap, &n_out, nullptr));
+    int rc = 1;
+    if (!both && c->short_sort) {
+        const int rb = sort_rbits(c);
+        const int T = rb * ((ilog2_ceil(n_bytes) + 3 + rb - 1) / rb);
+        if (T < 2 * K) {
+            rc = kmerize_short(c, stream, n_bytes, K, 2 * K - T, buf_a, buf_b, cap_keys, out_k, out_c, cap, st, &n_out);
+            if (rc < 0) return rc;
+            if (rc == 1) st->n_canonical = 0;      // side list overflowed: do it the long way
         }
     }
+    if (rc == 1) ZK_TRY(kmerize_full(c, stream, n_bytes, K, both, buf_a, buf_b, cap_keys, out_k, out_c, cap, st, &n_out));
     if (flags & ZK_KMERIZE_SUBSAMPLE) {
         uint64_t kept = 0;
         ZK_TRY(subsample_pairs(c, out_k, out_c, n_out, seed, p, &kept));

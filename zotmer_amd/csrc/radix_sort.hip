@@ -50,12 +50,12 @@ struct PassPlan {
     int bits[MAX_PASSES];
 };
 
-static PassPlan make_plan(int key_bits, int rbits) {
+static PassPlan make_plan(int key_bits, int rbits, int lo = 0) {
     PassPlan p;
     if (key_bits < 1) key_bits = 1;
     if (key_bits > 64) key_bits = 64;
     p.passes = (key_bits + rbits - 1) / rbits;
-    int base = key_bits / p.passes, rem = key_bits % p.passes, s = 0;
+    int base = key_bits / p.passes, rem = key_bits % p.passes, s = lo;
     for (int i = 0; i < MAX_PASSES; i++) { p.shift[i] = 0; p.bits[i] = 0; }
     for (int i = 0; i < p.passes; i++) {
         p.bits[i] = base + (i < rem ? 1 : 0);
@@ -561,7 +561,7 @@ struct Sorter {
     // pass read the stream, the remaining passes ping-pong between buf_a and buf_b.
     static int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,
                            uint64_t acgt[4], u64** result) {
-        PassPlan plan = make_plan(2 * src.K, C::RBITS);
+        PassPlan plan = make_plan(2 * src.K - src.lo_bit, C::RBITS, src.lo_bit);
         u64* ghist;
         ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * C::RADIX, (void**)&ghist));
         SortArgs a = {};
@@ -624,6 +624,11 @@ int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n,
     *rk = keys; *rv = vals;
     if (n == 0) return ZK_OK;
     ZK_SORT_DISPATCH_V(c->pairs_variant, sort_pairs(c, keys, alt, vals, valt, n, key_bits, rk, rv));
+}
+
+// digit width of the geometry used for key arrays (the truncated sort sizes its bit range with it)
+int sort_rbits(zk_ctx* c) {
+    switch (c->sort_variant) { case 3: case 5: return 9; default: return 8; }
 }
 
 int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,

@@ -172,6 +172,262 @@ __global__ __launch_bounds__(RLE_BLOCK) void rle_kernel(const u64* keys, u64 n, 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// K4': run-length count of an array that is sorted by its top bits only (prefix = key >> pshift).
+//
+// The radix sort is stopped early: with T >= log2(n) + 3.5 sorted bits almost every group of equal
+// prefix holds ONE distinct k-mer, so it is already where a full sort would put it.  A group is
+// written to the sorted main list iff it lies inside one tile and is uniform (one distinct key);
+// every other group -- mixed, or cut by a tile edge -- is appended, entry by entry, to an unordered
+// side list that the caller sorts with the strand mirror (which it has to sort anyway).  Whatever
+// the input, the two lists together hold every (k-mer, run length) exactly once; only how much lands
+// in the side list depends on the data.
+// ---------------------------------------------------------------------------------------
+constexpr int PFX_WORDS = RLE_TILE / 64;
+
+struct PfxSmem {
+    SelSmemT<RLE_NW> sel;
+    u64 fh[PFX_WORDS];      // full-key heads, one bit per tile position
+    u64 ph[PFX_WORDS];      // prefix heads
+    u8 cls[RLE_TILE];       // per group start: 1 = goes to the main list
+    u32 wside[RLE_NW];
+    u64 side_base;
+};
+
+__device__ __forceinline__ int bits_prev(const u64* b, int p) {          // largest set q <= p, or -1
+    int w = p >> 6;
+    u64 m = b[w] & (~0ull >> (63 - (p & 63)));
+    while (true) {
+        if (m) return (w << 6) + 63 - __builtin_clzll(m);
+        if (--w < 0) return -1;
+        m = b[w];
+    }
+}
+__device__ __forceinline__ int bits_next(const u64* b, int p, int limit) {   // smallest set q > p below limit, or limit
+    if (p + 1 >= limit) return limit;
+    int w = (p + 1) >> 6;
+    u64 m = b[w] & (~0ull << ((p + 1) & 63));
+    const int lw = (limit - 1) >> 6;
+    while (true) {
+        if (m) { const int q = (w << 6) + __builtin_ctzll(m); return q < limit ? q : limit; }
+        if (++w > lw) return limit;
+        m = b[w];
+    }
+}
+
+__global__ __launch_bounds__(RLE_BLOCK) void rle_prefix_kernel(const u64* keys, u64 n, int pshift, u64* uniq, u32* __restrict__ counts,
+                                                               u64 cap, u64* __restrict__ side_k, u32* __restrict__ side_c, u64 side_cap,
+                                                               u64* side_n, SelState st) {
+    __shared__ PfxSmem sm;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 tile = take_ticket(st.ticket, &sm.sel.ticket) - st.ticket_base;
+    const u64 tile_base = (u64)tile * RLE_TILE;
+    const u32 wave_rel = (u32)wave * (64 * RLE_ITEMS);
+    const u64 base = tile_base + wave_rel;
+    const u64 rem = n - tile_base;
+    const int tile_len = rem < (u64)RLE_TILE ? (int)rem : RLE_TILE;
+
+    u64 k[RLE_ITEMS];
+#pragma unroll
+    for (int i = 0; i < RLE_ITEMS; i++) {
+        const u64 idx = base + (u64)i * 64 + lane;
+        k[i] = (idx < n) ? keys[idx] : 0ull;
+    }
+#pragma unroll
+    for (int i = 0; i < RLE_ITEMS; i++) {
+        const u64 idx = base + (u64)i * 64 + lane;
+        u64 prev = __shfl_up(k[i], 1, 64);
+        if (i > 0) {
+            const u64 last = __shfl(k[i - 1], 63, 64);
+            if (lane == 0) prev = last;
+        } else if (lane == 0) {
+            prev = (idx > 0 && idx < n) ? keys[idx - 1] : 0ull;
+        }
+        const bool in = idx < n;
+        const bool fhead = in && (idx == 0 || k[i] != prev);
+        const bool phead = in && (idx == 0 || (k[i] >> pshift) != (prev >> pshift));
+        const u64 fm = __ballot(fhead), pm = __ballot(phead);
+        if (lane == 0) { sm.fh[wave * RLE_ITEMS + i] = fm; sm.ph[wave * RLE_ITEMS + i] = pm; }
+    }
+    // does the group that is open at the end of the tile continue in the next one?
+    bool cont_right = false;
+    if (threadIdx.x == 0) {
+        const u64 nxt = tile_base + (u64)tile_len;
+        if (nxt < n && tile_len > 0) cont_right = (keys[nxt] >> pshift) == (keys[nxt - 1] >> pshift);
+        sm.wside[0] = cont_right ? 1u : 0u;      // parked here until the barrier below
+    }
+    __syncthreads();
+    cont_right = sm.wside[0] != 0;
+    __syncthreads();
+
+    // ---- classify every group by its first element (a prefix head) -------------------------------
+#pragma unroll
+    for (int i = 0; i < RLE_ITEMS; i++) {
+        const int p = (int)wave_rel + i * 64 + lane;
+        if (p < tile_len && ((sm.ph[p >> 6] >> (p & 63)) & 1ull)) {
+            const int ge = bits_next(sm.ph, p, tile_len);             // first position of the next group, or tile_len
+            const bool open_right = (ge == tile_len) && cont_right;
+            const bool mixed = bits_next(sm.fh, p, ge) < ge;            // another full head inside the group
+            sm.cls[p] = (!open_right && !mixed) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+
+    // ---- every full head is one (key, run length) entry: main or side ------------------------------
+    u64 mm[RLE_ITEMS];           // main entries of the row
+    u64 sd[RLE_ITEMS];           // side entries of the row
+    u32 len[RLE_ITEMS];
+    u32 wave_main = 0, wave_side = 0;
+#pragma unroll
+    for (int i = 0; i < RLE_ITEMS; i++) {
+        const int p = (int)wave_rel + i * 64 + lane;
+        bool is_main = false, is_side = false;
+        len[i] = 0;
+        if (p < tile_len && ((sm.fh[p >> 6] >> (p & 63)) & 1ull)) {
+            const int nx = bits_next(sm.fh, p, tile_len);
+            len[i] = (u32)(nx - p);
+            const int gs = bits_prev(sm.ph, p);                        // start of my group, -1: it began in an earlier tile
+            is_main = (gs >= 0) && sm.cls[gs];
+            is_side = !is_main;
+        }
+        mm[i] = __ballot(is_main);
+        sd[i] = __ballot(is_side);
+        wave_main += (u32)__popcll(mm[i]);
+        wave_side += (u32)__popcll(sd[i]);
+    }
+    // leading elements of the tile that continue the previous tile's last RUN (no full head of their
+    // own) form one more side entry, owned by thread 0
+    int lead_len = 0;
+    if (threadIdx.x == 0 && tile_len > 0 && !(sm.fh[0] & 1ull)) lead_len = bits_next(sm.fh, 0, tile_len);
+    if (lane == 0) sm.wside[wave] = wave_side + (lead_len ? 1u : 0u);
+
+    u32 tile_main;
+    const u64 wbase = select_wave_base(sm.sel, st, tile, wave_main, &tile_main);     // barriers inside
+    if (threadIdx.x == 0) {
+        u32 tot = 0;
+#pragma unroll
+        for (int w = 0; w < RLE_NW; w++) tot += sm.wside[w];
+        sm.side_base = tot ? atomicAdd(side_n, (u64)tot) : 0ull;
+    }
+    __syncthreads();
+    u32 sex = 0;
+#pragma unroll
+    for (int w = 0; w < RLE_NW; w++) if (w < wave) sex += sm.wside[w];
+    u64 qm = wbase, qs = sm.side_base + sex;
+    if (lead_len) {                                   // thread 0 only; k[0] is the tile's first key
+        if (qs < side_cap) { side_k[qs] = k[0]; side_c[qs] = (u32)lead_len; }
+    }
+    if (wave == 0) qs += (sm.wside[0] > wave_side) ? 1 : 0;     // wave 0's entries follow the lead entry
+#pragma unroll
+    for (int i = 0; i < RLE_ITEMS; i++) {
+        if ((mm[i] >> lane) & 1ull) {
+            const u64 pos = qm + popc_below(mm[i]);
+            if (pos < cap) { uniq[pos] = k[i]; counts[pos] = len[i]; }
+        }
+        if ((sd[i] >> lane) & 1ull) {
+            const u64 pos = qs + popc_below(sd[i]);
+            if (pos < side_cap) { side_k[pos] = k[i]; side_c[pos] = len[i]; }
+        }
+        qm += (u32)__popcll(mm[i]);
+        qs += (u32)__popcll(sd[i]);
+    }
+    if (threadIdx.x == 0 && tile == st.tiles - 1 && sm.sel.tile_excl + tile_main > cap) atomicOr(st.err, ZK_DERR_CAPACITY);
+}
+
+int rle_prefix(zk_ctx* c, const u64* sorted, uint64_t n, int pshift, u64* uniq, u32* counts, uint64_t cap, uint64_t* n_main,
+               u64* side_k, u32* side_c, uint64_t side_cap, uint64_t* n_side) {
+    *n_main = 0; *n_side = 0;
+    if (n == 0) return ZK_OK;
+    SelState st;
+    st.tiles = (u32)div_up(n, RLE_TILE);
+    ZK_TRY(lookback_begin(c, st.tiles, st.tiles, &st.epoch, &st.ticket_base));
+    st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9;
+    u64* d_side = c->d_scalars + 10;
+    ZK_HIP(c, hipMemsetAsync(d_side, 0, sizeof(u64), c->stream));
+    prof_begin(c, ZK_PROF_RLE, 8 * n);
+    hipLaunchKernelGGL(rle_prefix_kernel, dim3(st.tiles), dim3(RLE_BLOCK), 0, c->stream, sorted, (u64)n, pshift, uniq, counts, (u64)cap,
+                       side_k, side_c, (u64)side_cap, d_side, st);
+    prof_end(c);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, c->d_scalars + 9, 2 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    *n_main = c->h_scalars[9];
+    *n_side = c->h_scalars[10];
+    return check_device_error(c);
+}
+
+// ---------------------------------------------------------------------------------------
+// sum the payloads of equal adjacent keys: (sorted keys with duplicates, w) -> (distinct keys, sums).
+// Element i belongs to run number (heads up to and including i) - 1; its weight goes there with one
+// atomic add (runs are short: a k-mer and its mirror, or the pieces of a run that crossed tiles).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SEL_BLOCK) void reduce_by_key_kernel(const u64* __restrict__ keys, const u32* __restrict__ w, u64 n,
+                                                                  u64* __restrict__ uniq, u32* sums, u64 cap, SelState st) {
+    __shared__ SelSmem sm;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 tile = take_ticket(st.ticket, &sm.ticket) - st.ticket_base;
+    const u64 base = (u64)tile * SEL_TILE + (u64)wave * (64 * SEL_ITEMS);
+    u64 k[SEL_ITEMS];
+    u32 wt[SEL_ITEMS];
+    u64 hm[SEL_ITEMS];
+    u32 wave_total = 0;
+#pragma unroll
+    for (int i = 0; i < SEL_ITEMS; i++) {
+        const u64 idx = base + (u64)i * 64 + lane;
+        k[i] = (idx < n) ? keys[idx] : 0ull;
+        wt[i] = (idx < n) ? w[idx] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < SEL_ITEMS; i++) {
+        const u64 idx = base + (u64)i * 64 + lane;
+        u64 prev = __shfl_up(k[i], 1, 64);
+        if (i > 0) {
+            const u64 last = __shfl(k[i - 1], 63, 64);
+            if (lane == 0) prev = last;
+        } else if (lane == 0) {
+            prev = (idx > 0 && idx < n) ? keys[idx - 1] : 0ull;
+        }
+        const bool head = (idx < n) && (idx == 0 || k[i] != prev);
+        hm[i] = __ballot(head);
+        wave_total += (u32)__popcll(hm[i]);
+    }
+    u32 tile_total;
+    u64 q = select_wave_base(sm, st, tile, wave_total, &tile_total);
+#pragma unroll
+    for (int i = 0; i < SEL_ITEMS; i++) {
+        const u64 idx = base + (u64)i * 64 + lane;
+        if (idx < n) {
+            const u64 incl = q + popc_below(hm[i]) + ((hm[i] >> lane) & 1ull);     // heads up to and including me
+            const u64 run = incl - 1;                                              // incl >= 1: element 0 is a head
+            if (run < cap) {
+                if ((hm[i] >> lane) & 1ull) uniq[run] = k[i];
+                const u32 old = atomicAdd(&sums[run], wt[i]);
+                if (old + wt[i] < old) atomicOr(st.err, ZK_DERR_COUNT_OVERFLOW);
+            }
+        }
+        q += (u32)__popcll(hm[i]);
+    }
+    if (threadIdx.x == 0 && tile == st.tiles - 1 && sm.tile_excl + tile_total > cap) atomicOr(st.err, ZK_DERR_CAPACITY);
+}
+
+int reduce_by_key(zk_ctx* c, const u64* sorted, const u32* w, uint64_t n, u64* uniq, u32* sums, uint64_t cap, uint64_t* n_out) {
+    *n_out = 0;
+    if (n == 0) return ZK_OK;
+    SelState st;
+    st.tiles = (u32)div_up(n, SEL_TILE);
+    ZK_TRY(lookback_begin(c, st.tiles, st.tiles, &st.epoch, &st.ticket_base));
+    st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9;
+    ZK_HIP(c, hipMemsetAsync(sums, 0, sizeof(u32) * (n < cap ? n : cap), c->stream));
+    prof_begin(c, ZK_PROF_SELECT, 12 * n);
+    hipLaunchKernelGGL(reduce_by_key_kernel, dim3(st.tiles), dim3(SEL_BLOCK), 0, c->stream, sorted, w, (u64)n, uniq, sums, (u64)cap, st);
+    prof_end(c);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, c->d_scalars + 9, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    *n_out = c->h_scalars[9];
+    return check_device_error(c);
+}
+
 // counts[(first output index of tile t) - 1] += lead[t]
 __global__ void rle_fixup_kernel(const u32* __restrict__ lead, const u64* __restrict__ status, u32 tiles, u32* counts,
                                  u64 cap, u32* err) {

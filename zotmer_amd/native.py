@@ -147,7 +147,8 @@ class Context:
         self.lib = load()
         self.h = self.lib.zk_create(device, workspace_bytes)
         if not self.h:
-            raise ZotkError(ZK_EHIP, "zk_create(%d) failed: no MI355X visible to HIP (there is no CPU fallback)" % device)
+            why = self.lib.zk_last_error(None).decode(errors="replace")
+            raise ZotkError(ZK_EHIP, "zk_create(%d) failed: %s -- no usable MI355X (there is no CPU fallback)" % (device, why))
         self.device = device
 
     def close(self):
@@ -199,7 +200,11 @@ class Context:
     PROF_TAGS = {"hist_stream": 1, "hist_array": 2, "pass_stream": 3, "pass_keys": 4, "pass_pairs": 5, "rle": 6,
                  "union_sum": 7, "select": 8, "mirror": 9, "intersect": 10, "count_hist": 11}
 
-    def tune(self, sort_variant=None, pairs_variant=None):
+    def tune(self, sort_variant=None, pairs_variant=None, short_sort=None, side_div=None):
+        if short_sort is not None:
+            self._check(self.lib.zk_tune(self.h, 3, int(short_sort)))
+        if side_div is not None:
+            self._check(self.lib.zk_tune(self.h, 4, int(side_div)))
         if sort_variant is not None:
             self._check(self.lib.zk_tune(self.h, 1, int(sort_variant)))
         if pairs_variant is not None:

@@ -78,6 +78,7 @@ class RangeExchange:
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
         self.ops = ops if ops is not None else GpuOps(ctx)
         self.cuts = splitters(K, self.world)
+        self._rk = self._rc = None        # receive buffers, kept between steps (grown on demand)
 
     def exchange(self, keys_t, counts_t, n):
         """keys_t (int64) / counts_t (int32): this rank's sorted table in its first n entries.
@@ -91,8 +92,11 @@ class RangeExchange:
         dist.all_to_all_single(r, s)
         recv = [int(v) for v in r.tolist()]
         total = sum(recv)
-        rk = ops.empty(total, torch.int64)
-        rc = ops.empty(total, torch.int32)
+        if self._rk is None or self._rk.numel() < total:
+            self._rk = self._rc = None
+            self._rk = ops.empty(total + total // 16, torch.int64)
+            self._rc = ops.empty(total + total // 16, torch.int32)
+        rk, rc = self._rk, self._rc
         dist.all_to_all_single(rk[:total], keys_t[:n], recv, send)
         dist.all_to_all_single(rc[:total], counts_t[:n], recv, send)
         ops.after_comm()
