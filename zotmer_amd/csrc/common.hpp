@@ -133,6 +133,18 @@ __device__ __forceinline__ u64 lookback_exclusive(u64* status, u32 tile, u64 tot
     return excl;
 }
 
+// Sum of v over the workgroup, valid in thread 0 (scratch: one u64 per wave).  Ends with a barrier.
+__device__ __forceinline__ u64 block_sum_u64(u64 v, u64* scratch) {
+    v = wave_sum_u64(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    u64 t = 0;
+    if (threadIdx.x == 0) for (int w = 0; w < nw; w++) t += scratch[w];
+    __syncthreads();
+    return t;
+}
+
 // reverse the 32 bit-pairs of a word (bits.rev, zotmer/library/bits.py:22-31)
 __device__ __forceinline__ u64 rev_pairs(u64 x) {
     u64 y = __brevll(x);

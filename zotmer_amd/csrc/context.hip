@@ -28,8 +28,10 @@ int arena_alloc(zk_ctx* c, uint64_t bytes, void** p) {
         // nothing handed out yet in this call: safe to regrow
         ZK_HIP(c, hipStreamSynchronize(c->stream));
         if (c->arena) { ZK_HIP(c, hipFree(c->arena)); c->arena = nullptr; c->arena_size = 0; }
-        ZK_HIP(c, hipMalloc((void**)&c->arena, need));
-        c->arena_size = need;
+        const uint64_t floor_bytes = 64ull << 20;       // small follow-up allocations of the same call must fit too
+        const uint64_t want = need + (need < floor_bytes ? floor_bytes : need / 16);
+        ZK_HIP(c, hipMalloc((void**)&c->arena, want));
+        c->arena_size = want;
     }
     *p = c->arena + c->arena_off;
     c->arena_off += need;

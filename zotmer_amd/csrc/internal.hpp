@@ -110,5 +110,6 @@ int count_hist(zk_ctx* c, const void* counts, int count_bits, uint64_t n, uint64
 // setops.hip
 int union_sum(zk_ctx* c, const u64* A, const void* cA, u64 nA, const u64* B, const void* cB, u64 nB, u64* ok, void* oc,
               int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);
+int column_sum(zk_ctx* c, const u64* rows, uint64_t n_rows, int cols, u64* out);   // out[c] = sum of rows[r][c]
 int intersect_count(zk_ctx* c, const u64* A, u64 nA, const u64* B, u64 nB, uint64_t abc[3]);
 }  // namespace zk

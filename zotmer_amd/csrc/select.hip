@@ -617,16 +617,13 @@ __global__ __launch_bounds__(SEL_BLOCK) void encode_list_kernel(const u8* __rest
         }
         pos += (u32)__popcll(km[i]);
     }
-    if (acgt) {
-        a0 = wave_sum_u32(a0); a1 = wave_sum_u32(a1); a2 = wave_sum_u32(a2); a3 = wave_sum_u32(a3);
-        if (lane == 0) {
-            if (a0) atomicAdd(&acgt[0], (u64)a0);
-            if (a1) atomicAdd(&acgt[1], (u64)a1);
-            if (a2) atomicAdd(&acgt[2], (u64)a2);
-            if (a3) atomicAdd(&acgt[3], (u64)a3);
-        }
-    }
     if (threadIdx.x == 0 && tile == st.tiles - 1 && (sm.tile_excl + tile_total) * mul > cap) atomicOr(st.err, ZK_DERR_CAPACITY);
+    if (acgt) {      // one partial row per tile, summed afterwards (no contended atomics)
+        __shared__ u64 scratch[SEL_NW];
+        const u64 t0 = block_sum_u64(a0, scratch), t1 = block_sum_u64(a1, scratch), t2 = block_sum_u64(a2, scratch),
+                  t3 = block_sum_u64(a3, scratch);
+        if (threadIdx.x == 0) { u64* row = acgt + 4ull * tile; row[0] = t0; row[1] = t1; row[2] = t2; row[3] = t3; }
+    }
 }
 
 int encode_list(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int both, u64* out, uint64_t cap, uint64_t* n_out,
@@ -639,11 +636,12 @@ int encode_list(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int both, 
     st.tiles = (u32)div_up(n_bytes, SEL_TILE);
     ZK_TRY(lookback_begin(c, st.tiles, st.tiles, &st.epoch, &st.ticket_base));
     st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9;
-    u64* d_acgt = c->d_scalars + 0;
-    ZK_HIP(c, hipMemsetAsync(d_acgt, 0, 4 * sizeof(u64), c->stream));
+    u64* d_rows;
+    ZK_TRY(arena_alloc(c, 32ull * st.tiles, (void**)&d_rows));
     hipLaunchKernelGGL(encode_list_kernel, dim3(st.tiles), dim3(SEL_BLOCK), 0, c->stream, stream, (u64)n_bytes, K, both, out,
-                       (u64)cap, d_acgt, st);
+                       (u64)cap, d_rows, st);
     ZK_HIP(c, hipGetLastError());
+    ZK_TRY(column_sum(c, d_rows, st.tiles, 4, c->d_scalars + 0));
     ZK_HIP(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(u64) * 16, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     *n_out = c->h_scalars[9] * (both ? 2 : 1);
@@ -771,6 +769,7 @@ int count_hist(zk_ctx* c, const void* counts, int count_bits, uint64_t n, uint64
     if (n == 0) return ZK_OK;
     const uint64_t big_cap = n < (1ull << 22) ? n : (1ull << 22);
     u64 *dense, *big;
+    ZK_TRY(arena_require(c, sizeof(u64) * (HIST_DENSE + big_cap) + 4096, sizeof(u64) * (HIST_DENSE + big_cap) + 4096));
     ZK_TRY(arena_alloc(c, sizeof(u64) * HIST_DENSE, (void**)&dense));
     ZK_TRY(arena_alloc(c, sizeof(u64) * big_cap, (void**)&big));
     u64* big_n = c->d_scalars + 10;
