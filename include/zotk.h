@@ -160,9 +160,10 @@ int zk_union_sum(zk_ctx* ctx, const uint64_t* d_xk, const void* d_xc, uint64_t n
                  uint64_t* d_ok, void* d_oc, int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);
 
 /* mergeNinto (commands/merge.py:127-163; twin commands/kmerize.py:269-304): k sorted-unique lists
- * with 64-bit counts -> one.  d_keys / d_counts / ns are HOST arrays of k device pointers / sizes. */
-int zk_merge_n(zk_ctx* ctx, int k, const uint64_t* const* d_keys, const uint64_t* const* d_counts, const uint64_t* ns,
-               uint64_t* d_ok, uint64_t* d_oc, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);
+ * -> one.  d_keys / d_counts / ns are HOST arrays of k device pointers / sizes; count_bits (32 or 64)
+ * is the element type of every count array. */
+int zk_merge_n(zk_ctx* ctx, int k, const uint64_t* const* d_keys, const void* const* d_counts, const uint64_t* ns,
+               uint64_t* d_ok, void* d_oc, int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);
 
 /* ---- K8/K9: dist ------------------------------------------------------------------------------- */
 

@@ -50,7 +50,8 @@ def main():
         c = rng.geometric(1 / 8.0, size=len(k)).astype(np.uint64)
         sets.append((ctx.upload(k), ctx.upload(c)))
     tot = sum(s[0].n for s in sets)
-    t, r = timed(ctx, lambda: ctx.merge_n(sets), reps=3)
+    mk, mc = ctx.empty(tot, np.uint64), ctx.empty(tot, np.uint64)
+    t, r = timed(ctx, lambda: ctx.merge_n(sets, out=(mk, mc)), reps=3)
     out["merge_8x50M"] = dict(ms=t * 1e3, total_in=tot, out=r[0].n, Gpairs_per_s=tot / t / 1e9,
                               GBps_model_3_levels=(3 * 16 * tot + 16 * r[0].n) / t / 1e9)
     print(json.dumps(out, indent=1))

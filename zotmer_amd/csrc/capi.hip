@@ -6,8 +6,8 @@
 namespace zk {
 int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, double p, uint64_t seed, u64* out_k, u32* out_c,
             uint64_t cap, zk_kmerize_stats* st);
-int merge_many(zk_ctx* c, int k, const u64* const* keys, const u64* const* cnts, const uint64_t* ns, u64* out_k, u64* out_c,
-               uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);
+int merge_many(zk_ctx* c, int k, const u64* const* keys, const void* const* cnts, const uint64_t* ns, u64* out_k, void* out_c,
+               int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);
 int widen_counts(zk_ctx* c, const u32* in, u64* out, uint64_t n);
 
 // ---- (bases, offsets) -> base stream ----------------------------------------------------------
@@ -216,10 +216,10 @@ int zk_union_sum(zk_ctx* c, const uint64_t* d_xk, const void* d_xc, uint64_t nx,
     return union_sum(c, (const u64*)d_xk, d_xc, nx, (const u64*)d_yk, d_yc, ny, (u64*)d_ok, d_oc, count_bits, cap, n_out, acgt_w);
 }
 
-int zk_merge_n(zk_ctx* c, int k, const uint64_t* const* d_keys, const uint64_t* const* d_counts, const uint64_t* ns,
-               uint64_t* d_ok, uint64_t* d_oc, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]) {
-    ZK_ARGS(c, n_out && k >= 0);
-    return merge_many(c, k, (const u64* const*)d_keys, (const u64* const*)d_counts, ns, (u64*)d_ok, (u64*)d_oc, cap, n_out, acgt_w);
+int zk_merge_n(zk_ctx* c, int k, const uint64_t* const* d_keys, const void* const* d_counts, const uint64_t* ns,
+               uint64_t* d_ok, void* d_oc, int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]) {
+    ZK_ARGS(c, n_out && k >= 0 && (count_bits == 32 || count_bits == 64));
+    return merge_many(c, k, (const u64* const*)d_keys, d_counts, ns, (u64*)d_ok, d_oc, count_bits, cap, n_out, acgt_w);
 }
 
 int zk_project_dedupe(zk_ctx* c, const uint64_t* d_kmers, uint64_t n, int shift, uint64_t* d_out, uint64_t cap, uint64_t* n_out) {

@@ -184,10 +184,11 @@ int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, dou
     return check_device_error(c);
 }
 
-// k-way union-sum as a balanced tree of 2-way passes; counts are 64-bit.
+// k-way union-sum as a balanced tree of 2-way passes; counts are 32- or 64-bit (count_bits).
 // ins: k device arrays (keys, counts, n).  The result lands in (out_k, out_c).
-int merge_many(zk_ctx* c, int k, const u64* const* keys, const u64* const* cnts, const uint64_t* ns, u64* out_k, u64* out_c,
-               uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]) {
+int merge_many(zk_ctx* c, int k, const u64* const* keys, const void* const* cnts, const uint64_t* ns, u64* out_k, void* out_c,
+               int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]) {
+    const uint64_t cb = (uint64_t)count_bits / 8;
     *n_out = 0;
     if (acgt_w) acgt_w[0] = acgt_w[1] = acgt_w[2] = acgt_w[3] = 0;
     if (k <= 0) return ZK_OK;
@@ -196,14 +197,14 @@ int merge_many(zk_ctx* c, int k, const u64* const* keys, const u64* const* cnts,
     for (int i = 0; i < k; i++) total += ns[i];
     if (k == 1) {
         // union with the empty set: a plain copy that also yields the count-weighted acgt
-        return union_sum(c, keys[0], cnts[0], ns[0], keys[0], cnts[0], 0, out_k, out_c, 64, cap, n_out, acgt_w);
+        return union_sum(c, keys[0], cnts[0], ns[0], keys[0], cnts[0], 0, out_k, out_c, count_bits, cap, n_out, acgt_w);
     }
     // two ping-pong regions, each able to hold every intermediate list of one level
     const uint64_t slack = 1 << 20;
-    const uint64_t rbytes = 16 * total + 512ull * k;
-    const uint64_t need = 2 * rbytes + total / 8 + 8192ull * k + slack;   // + merge-path partitions
+    const uint64_t rbytes = (8 + cb) * total + 512ull * k;
+    const uint64_t need = 2 * rbytes + total / 8 + total / 32 + 8192ull * k + slack;   // + merge-path partitions, acgt rows
     ZK_TRY(arena_require(c, need, need));
-    struct L { const u64* k; const u64* c; uint64_t n; };
+    struct L { const u64* k; const void* c; uint64_t n; };
     std::vector<L> va(k), vb(k);
     L* cur = va.data();
     L* nxt = vb.data();
@@ -223,15 +224,15 @@ int merge_many(zk_ctx* c, int k, const u64* const* keys, const u64* const* cnts,
         int o = 0;
         for (int i = 0; i + 1 < m; i += 2) {
             const uint64_t cap2 = cur[i].n + cur[i + 1].n;
-            u64* ok; u64* oc; uint64_t capo;
+            u64* ok; void* oc; uint64_t capo;
             if (last) { ok = out_k; oc = out_c; capo = cap; }
             else {
                 ok = (u64*)(base + off); off += (8 * cap2 + 255) & ~255ull;
-                oc = (u64*)(base + off); off += (8 * cap2 + 255) & ~255ull;
+                oc = (void*)(base + off); off += (cb * cap2 + 255) & ~255ull;
                 capo = cap2;
             }
             uint64_t no = 0;
-            ZK_TRY(union_sum(c, cur[i].k, cur[i].c, cur[i].n, cur[i + 1].k, cur[i + 1].c, cur[i + 1].n, ok, oc, 64, capo, &no,
+            ZK_TRY(union_sum(c, cur[i].k, cur[i].c, cur[i].n, cur[i + 1].k, cur[i + 1].c, cur[i + 1].n, ok, oc, count_bits, capo, &no,
                              last ? acgt_w : nullptr));
             nxt[o++] = L{ok, oc, no};
         }
@@ -241,9 +242,9 @@ int merge_many(zk_ctx* c, int k, const u64* const* keys, const u64* const* cnts,
             L x = cur[m - 1];
             if (in_regions(x.k)) {
                 u64* ok = (u64*)(base + off); off += (8 * x.n + 255) & ~255ull;
-                u64* oc = (u64*)(base + off); off += (8 * x.n + 255) & ~255ull;
+                void* oc = (void*)(base + off); off += (cb * x.n + 255) & ~255ull;
                 ZK_HIP(c, hipMemcpyAsync(ok, x.k, 8 * x.n, hipMemcpyDeviceToDevice, c->stream));
-                ZK_HIP(c, hipMemcpyAsync(oc, x.c, 8 * x.n, hipMemcpyDeviceToDevice, c->stream));
+                ZK_HIP(c, hipMemcpyAsync(oc, x.c, cb * x.n, hipMemcpyDeviceToDevice, c->stream));
                 x.k = ok; x.c = oc;
             }
             nxt[o++] = x;

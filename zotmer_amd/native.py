@@ -69,7 +69,7 @@ SIGNATURES = {
     "zk_hist": (_i, [_vp, _vp, _i, _u64, _pu64, _pu64, _u64, _pu64]),
     "zk_widen_counts": (_i, [_vp, _vp, _vp, _u64]),
     "zk_union_sum": (_i, [_vp, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _i, _u64, _pu64, _pu64]),
-    "zk_merge_n": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _pu64, _vp, _vp, _u64, _pu64, _pu64]),
+    "zk_merge_n": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _pu64, _vp, _vp, _i, _u64, _pu64, _pu64]),
     "zk_project_dedupe": (_i, [_vp, _vp, _u64, _i, _vp, _u64, _pu64]),
     "zk_split": (_i, [_vp, _vp, _u64, _vp, _u64, _pu64]),
     "zk_lower_bound": (_i, [_vp, _vp, _u64, _pu64, _u32, _pu64]),
@@ -311,17 +311,24 @@ class Context:
         r = (ok.view(n.value), oc.view(n.value))
         return r + ([int(v) for v in acgt],) if want_acgt else r
 
-    def merge_n(self, sets):
-        """sets = [(kmers u64 DeviceArray, counts u64 DeviceArray), ...] -> (kmers, counts, acgt_weighted)."""
+    def merge_n(self, sets, out=None):
+        """sets = [(kmers u64 DeviceArray, counts u32|u64 DeviceArray), ...] -> (kmers, counts, acgt_weighted).
+        out = (kmers, counts) preallocated arrays to write into (their length is the capacity)."""
         k = len(sets)
+        cdt = sets[0][1].dtype if k else np.dtype(np.uint64)
+        assert all(s[1].dtype == cdt for s in sets)
         pk = (_vp * k)(*[s[0].ptr for s in sets])
         pc = (_vp * k)(*[s[1].ptr for s in sets])
         ns = (C.c_uint64 * k)(*[s[0].n for s in sets])
-        cap = sum(s[0].n for s in sets)
-        ok, oc = self.empty(cap, np.uint64), self.empty(cap, np.uint64)
+        if out is None:
+            cap = sum(s[0].n for s in sets)
+            ok, oc = self.empty(cap, np.uint64), self.empty(cap, cdt)
+        else:
+            ok, oc = out
+            cap = min(ok.n, oc.n)
         n = C.c_uint64(0)
         acgt = (C.c_uint64 * 4)()
-        self._check(self.lib.zk_merge_n(self.h, k, pk, pc, ns, ok.ptr, oc.ptr, cap, C.byref(n), acgt))
+        self._check(self.lib.zk_merge_n(self.h, k, pk, pc, ns, ok.ptr, oc.ptr, cdt.itemsize * 8, cap, C.byref(n), acgt))
         return ok.view(n.value), oc.view(n.value), [int(v) for v in acgt]
 
     def project_dedupe(self, kmers, shift):

@@ -55,18 +55,21 @@ class GpuOps:
         torch.cuda.synchronize()
 
     def merge_segments(self, keys_t, counts_t, segs):
-        """Union-sum the sorted segments [(offset, length)] of the receive buffers pairwise."""
+        """k-way union-sum of the sorted segments [(offset, length)] of the receive buffers
+        (zk_merge_n: a tree of merge-path passes inside the library's workspace; the output buffers
+        are kept between steps, so a steady-state step allocates nothing)."""
         parts = [(self.k_array(keys_t, n, o), self.c_array(counts_t, n, o)) for o, n in segs if n]
         if not parts:
             return self.k_array(keys_t, 0), self.c_array(counts_t, 0)
-        while len(parts) > 1:
-            nxt = []
-            for i in range(0, len(parts) - 1, 2):
-                nxt.append(self.ctx.union_sum(parts[i][0], parts[i][1], parts[i + 1][0], parts[i + 1][1]))
-            if len(parts) & 1:
-                nxt.append(parts[-1])
-            parts = nxt
-        return parts[0]
+        if len(parts) == 1:
+            return parts[0]
+        total = sum(p[0].n for p in parts)
+        if getattr(self, "_mk", None) is None or self._mk.n < total:
+            self._mk = self._mc = None
+            self._mk = self.ctx.empty(total + total // 16, np.uint64)
+            self._mc = self.ctx.empty(total + total // 16, np.uint32)
+        k, c, _ = self.ctx.merge_n(parts, out=(self._mk, self._mc))
+        return k, c
 
     def checksum(self, k, c):
         return self.ctx.checksum(k, c)
