@@ -39,6 +39,23 @@ def model_bytes(n_stream_bytes, instances, unique, K):
     return n_stream_bytes + 8 * instances + (1 + 2 * P) * 8 * instances + 8 * instances + 12 * unique
 
 
+def measured_traffic(kernel_substr, n_keys_now):
+    """HBM bytes per launch of the dominant kernel from the committed PMC runs of THIS command
+    (profiles/r01_config2_final/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    passes, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950; tools/collect_traffic.py).  PMC
+    counters cannot be read from inside the timed run, so the figure is taken from that profile and only
+    reported when the workload (number of keys per launch) is the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01_config2_final", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    for name, v in d.items():
+        if kernel_substr in name and abs(v.get("n_keys", 0) - n_keys_now) <= 0.001 * max(n_keys_now, 1):
+            return v["traffic_bytes_per_launch"]
+    return None
+
+
 def cpu_baseline(cfg, seed, budget_s=12.0):
     """Single-core CPU oracle on a prefix of the same reads, sized to about budget_s seconds."""
     from oracle import zkoracle as zo
@@ -195,7 +212,10 @@ def main():
                        "parallelism": "1 gpu" if world == 1 else "reads sharded over %d gpus + value-range all-to-all" % world},
             "roofline": {"bound": "hbm", "kernel": "pass_kernel<array,keys> (one LSD radix pass, 16 B/key)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "launches": pk["launches"],
+                         "traffic": measured_traffic("pass_kernel<zk::Cfg<512, 16, 9, 0>, 0, false>", st.n_windows),
+                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, KiB) of this "
+                                         "command, profiles/r01_config2_final/pmc_traffic.json; null if the workload differs",
+                         "launches": pk["launches"],
                          "avg_launch_ms": pk["ms"] / pk["launches"] if pk["launches"] else None},
             "pipeline": {"windows_per_s": value * 1e9 / 2, "instances_per_step": st.n_instances, "unique": st.n_unique,
                          "canonical_unique": st.n_canonical, "model_bytes": mb,

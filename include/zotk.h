@@ -195,6 +195,13 @@ int zk_codec64_count(const uint64_t* words, uint64_t nw, uint64_t* n_values);
  * (files.undelta, library/files.py:100-110) */
 int zk_codec64_decode(const uint64_t* words, uint64_t nw, int delta, uint64_t* out, uint64_t cap, uint64_t* n_out);
 
+/* The same codec on the device (K11 / K12): values and words are DEVICE arrays; streams are byte-exact
+ * with the host functions above and with the reference.  encode: d_words needs at most n entries;
+ * decode: the exact value count comes back in *n_out, also with ZK_ENOSPC when it exceeds cap (so a first
+ * call with cap = 0 sizes the output). */
+int zk_codec64_encode_dev(zk_ctx* ctx, const uint64_t* d_vals, uint64_t n, int delta, uint64_t* d_words, uint64_t cap, uint64_t* n_words);
+int zk_codec64_decode_dev(zk_ctx* ctx, const uint64_t* d_words, uint64_t nw, int delta, uint64_t* d_out, uint64_t cap, uint64_t* n_out);
+
 /* file.readFastq / file.readFasta (library/file.py:19-52) as chunked text -> base stream converters.
  * state: 4 words, zero before the first chunk, state[1] = records seen.  Feed text; *consumed says how
  * much was used (present the rest again in front of the next chunk); final != 0 on the last chunk.

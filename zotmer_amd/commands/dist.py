@@ -59,8 +59,8 @@ def main(argv):
             fK = z.meta["K"]
             if fK < K:
                 raise MismatchedK(K, fK)
-            k = vectors.read_kmers(z)
-        return ctx.project_dedupe(ctx.upload(k), 2 * (fK - K))
+            k = vectors.device_read_kmers(ctx, z)
+        return ctx.project_dedupe(k, 2 * (fK - K))
 
     print("\t".join(["lhs.name", "rhs.name"] + ms))
     sets = {}

@@ -76,9 +76,9 @@ def main(argv):
     if verbose:
         sys.stderr.write("\n")
 
-    kmers, counts, hist = table.result()
-    with KmerSet(out, "w") as z:                    # kmerize.py:541-561
-        vectors.write_kmers_and_counts(z, kmers, counts)
+    kmers, counts, hist = table.device_result()
+    with KmerSet(out, "w") as z:                    # kmerize.py:541-561; delta + codec64 done on the device
+        vectors.device_write_kmers_and_counts(ctx, z, kmers, counts)
         total = float(sum(table.acgt))
         z.meta["K"] = K
         z.meta["kmers"] = "kmers"

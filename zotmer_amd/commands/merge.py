@@ -29,12 +29,11 @@ def main(argv):
             elif k0 != K:                           # merge.py:186-190
                 sys.stderr.write("mismatched K\n")
                 sys.exit(1)
-            k, c = vectors.read_kmers_and_counts(z)
-        sets.append((ctx.upload(k), ctx.upload(c)))
+            sets.append(vectors.device_read_kmers_and_counts(ctx, z))     # decoded on the device
     mk, mc, acgt = ctx.merge_n(sets)
     hist = ctx.hist(mc)
     with KmerSet(out, "w") as z:
-        vectors.write_kmers_and_counts(z, mk.to_host(), mc.to_host())
+        vectors.device_write_kmers_and_counts(ctx, z, mk, mc)
         total = float(sum(acgt))
         z.meta["K"] = K
         z.meta["kmers"] = "kmers"

@@ -58,10 +58,10 @@ def main(argv):
         if c == 0:
             c = infer(meta.get("hist", {}))
             sys.stderr.write("inferred cutoff: %d\n" % c)        # trim.py:85
-        k, cn = vectors.read_kmers_and_counts(z)
-    tk, tc = ctx.trim(ctx.upload(k), ctx.upload(cn), c, C if C > 0 else 0)
+        k, cn = vectors.device_read_kmers_and_counts(ctx, z)
+    tk, tc = ctx.trim(k, cn, c, C if C > 0 else 0)
     with KmerSet(opts["<output>"], "w") as w:
-        vectors.write_kmers_and_counts(w, tk.to_host(), tc.to_host())
+        vectors.device_write_kmers_and_counts(ctx, w, tk, tc)
         w.meta = meta
         w.meta["kmers"] = "kmers"
         w.meta["counts"] = "counts"

@@ -241,6 +241,18 @@ int zk_trim(zk_ctx* c, const uint64_t* d_kmers, const void* d_counts, int count_
     return trim(c, (const u64*)d_kmers, d_counts, count_bits, n, lo, hi, (u64*)d_ok, d_oc, cap, n_out);
 }
 
+int zk_codec64_encode_dev(zk_ctx* c, const uint64_t* d_vals, uint64_t n, int delta, uint64_t* d_words, uint64_t cap, uint64_t* n_words) {
+    ZK_ARGS(c, n_words);
+    arena_reset(c);
+    return codec_encode(c, (const u64*)d_vals, n, delta, (u64*)d_words, cap, n_words);
+}
+
+int zk_codec64_decode_dev(zk_ctx* c, const uint64_t* d_words, uint64_t nw, int delta, uint64_t* d_out, uint64_t cap, uint64_t* n_out) {
+    ZK_ARGS(c, n_out);
+    arena_reset(c);
+    return codec_decode(c, (const u64*)d_words, nw, delta, (u64*)d_out, cap, n_out);
+}
+
 int zk_lower_bound(zk_ctx* c, const uint64_t* d_sorted, uint64_t n, const uint64_t* queries, uint32_t m, uint64_t* positions) {
     ZK_ARGS(c, (m == 0) || (queries && positions));
     if (m == 0) return ZK_OK;

@@ -23,6 +23,8 @@ typedef unsigned char u8;
 #define ZK_DERR_SPIN_TIMEOUT 1u   // a look-back spin gave up (would otherwise hang)
 #define ZK_DERR_COUNT_OVERFLOW 2u // a 32-bit count wrapped
 #define ZK_DERR_CAPACITY 4u       // an output did not fit the caller's buffer
+#define ZK_DERR_RANGE 8u          // codec64: a value (or k-mer delta) >= 2^60 has no code
+#define ZK_DERR_BAD_TAG 16u       // codec64: a word carries a tag the format does not define
 
 namespace zk {
 

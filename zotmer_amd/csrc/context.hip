@@ -118,6 +118,8 @@ int check_device_error(zk_ctx* c) {
         c->epoch = 0;
         return fail(c, ZK_EINTERNAL, "device look-back spin limit reached (kernel bug or lost workgroup)");
     }
+    if (e & ZK_DERR_RANGE) return fail(c, ZK_ERANGE, "a value (or k-mer delta) >= 2^60 cannot be stored in the codec64 format");
+    if (e & ZK_DERR_BAD_TAG) return fail(c, ZK_ERANGE, "corrupt codec64 stream (unknown tag)");
     if (e & ZK_DERR_CAPACITY) return fail(c, ZK_ENOSPC, "output does not fit the capacity given");
     if (e & ZK_DERR_COUNT_OVERFLOW) return fail(c, ZK_EOVERFLOW, "a k-mer count does not fit the count type");
     return fail(c, ZK_EINTERNAL, "device error word 0x%x", e);

@@ -107,6 +107,9 @@ int reduce_by_key(zk_ctx* c, const u64* sorted, const u32* w, uint64_t n, u64* u
 int rle(zk_ctx* c, const u64* sorted, uint64_t n, u64* uniq, u32* counts, uint64_t cap, uint64_t* n_unique);
 int count_hist(zk_ctx* c, const void* counts, int count_bits, uint64_t n, uint64_t* vals, uint64_t* freq,
                uint64_t cap_bins, uint64_t* n_bins);
+// codec.hip
+int codec_decode(zk_ctx* c, const u64* d_words, uint64_t nw, int delta, u64* d_out, uint64_t cap, uint64_t* n_out);
+int codec_encode(zk_ctx* c, const u64* d_vals, uint64_t n, int delta, u64* d_words, uint64_t cap, uint64_t* n_words);
 // setops.hip
 int union_sum(zk_ctx* c, const u64* A, const void* cA, u64 nA, const u64* B, const void* cB, u64 nB, u64* ok, void* oc,
               int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);

@@ -87,6 +87,12 @@ class KmerTable:
             return np.empty(0, np.uint64), np.empty(0, np.uint32), {}
         return self.kmers.to_host(), self.counts.to_host(), self.ctx.hist(self.counts)
 
+    def device_result(self):
+        """(kmers, counts) as device arrays + hist, for the device codec."""
+        if self.kmers is None:
+            return self.ctx.empty(0, np.uint64), self.ctx.empty(0, np.uint32), {}
+        return self.kmers, self.counts, self.ctx.hist(self.counts)
+
 
 def _compact(ctx, k, c):
     """Copy views of oversized buffers into right-sized allocations."""

@@ -89,3 +89,52 @@ def write_kmers_and_counts(z, kmers, counts, name=None):
         kn, cn = "kmers", "counts"
     z.add(kn, encode_kmers(kmers))
     z.add(cn, encode_counts(counts))
+
+
+# ---- the same members through the device codec (K11 / K12): values never visit the host ----------------
+
+def _check_codec(fn, *a):
+    try:
+        return fn(*a)
+    except native.ZotkError as e:
+        if e.code == native.ZK_ERANGE:
+            raise CodecError(str(e))
+        raise
+
+
+def device_encode_kmers(ctx, kmers_dev):
+    """ascending uint64 k-mers on the device -> bytes of the 'kmers' member"""
+    if kmers_dev.n == 0:
+        return b""
+    return _check_codec(ctx.codec_encode, kmers_dev, True).to_host().astype("<u8", copy=False).tobytes()
+
+
+def device_encode_counts(ctx, counts_dev):
+    """uint32 / uint64 counts on the device -> bytes of the 'counts' member"""
+    if counts_dev.n == 0:
+        return b""
+    c64 = ctx.widen(counts_dev) if counts_dev.dtype.itemsize == 4 else counts_dev
+    return _check_codec(ctx.codec_encode, c64, False).to_host().astype("<u8", copy=False).tobytes()
+
+
+def device_write_kmers_and_counts(ctx, z, kmers_dev, counts_dev):
+    z.add("kmers", device_encode_kmers(ctx, kmers_dev))
+    z.add("counts", device_encode_counts(ctx, counts_dev))
+
+
+def device_read_kmers(ctx, z):
+    """'kmers' member -> uint64 k-mers on the device"""
+    data = z.read("kmers")
+    if not data:
+        return ctx.empty(0, np.uint64)
+    return _check_codec(ctx.codec_decode, ctx.upload(np.frombuffer(data, dtype="<u8")), True)
+
+
+def device_read_kmers_and_counts(ctx, z):
+    """(k-mers, counts) of a set as uint64 device arrays"""
+    k = device_read_kmers(ctx, z)
+    data = z.read("counts")
+    c = _check_codec(ctx.codec_decode, ctx.upload(np.frombuffer(data, dtype="<u8")), False) if data else ctx.empty(0, np.uint64)
+    if k.n != c.n:
+        raise CodecError("k-mer and count vectors differ in length (%d vs %d)" % (k.n, c.n))
+    return k, c

@@ -77,6 +77,8 @@ SIGNATURES = {
     "zk_codec64_encode": (_i, [_vp, _u64, _i, _vp, _u64, _pu64]),
     "zk_codec64_count": (_i, [_vp, _u64, _pu64]),
     "zk_codec64_decode": (_i, [_vp, _u64, _i, _vp, _u64, _pu64]),
+    "zk_codec64_encode_dev": (_i, [_vp, _vp, _u64, _i, _vp, _u64, _pu64]),
+    "zk_codec64_decode_dev": (_i, [_vp, _vp, _u64, _i, _vp, _u64, _pu64]),
     "zk_parse_fastq": (_i, [_vp, _u64, _i, _pu64, _vp, _u64, _pu64, _pu64]),
     "zk_parse_fasta": (_i, [_vp, _u64, _i, _pu64, _vp, _u64, _pu64, _pu64]),
     "zk_synth_reads": (_i, [_vp, _u64, _u64, _u64, _i, _u64, _u32, _u32, _vp]),
@@ -341,6 +343,25 @@ class Context:
         abc = (C.c_uint64 * 3)()
         self._check(self.lib.zk_split(self.h, x.ptr, x.n, y.ptr, y.n, abc))
         return tuple(int(v) for v in abc)
+
+    def codec_encode(self, values, delta):
+        """uint64 device values -> device codec64 words (delta=True: ascending k-mers, stored as differences)."""
+        words = self.empty(values.n, np.uint64)
+        n = C.c_uint64(0)
+        self._check(self.lib.zk_codec64_encode_dev(self.h, values.ptr, values.n, int(delta), words.ptr, words.n, C.byref(n)))
+        return words.view(n.value)
+
+    def codec_decode(self, words, delta, n_values=None):
+        """device codec64 words -> uint64 device values (delta=True also undoes the k-mer differences)."""
+        n = C.c_uint64(0)
+        if n_values is None:                 # a first pass with no output only counts
+            rc = self.lib.zk_codec64_decode_dev(self.h, words.ptr, words.n, 0, None, 0, C.byref(n))
+            if rc not in (ZK_OK, ZK_ENOSPC):
+                self._check(rc)
+            n_values = n.value
+        out = self.empty(n_values, np.uint64)
+        self._check(self.lib.zk_codec64_decode_dev(self.h, words.ptr, words.n, int(delta), out.ptr, int(n_values), C.byref(n)))
+        return out.view(n.value)
 
     def lower_bound(self, sorted_keys, queries):
         q = np.ascontiguousarray(queries, dtype=np.uint64)
