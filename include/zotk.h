@@ -211,6 +211,12 @@ int zk_parse_fastq(const char* buf, uint64_t len, int final, uint64_t state[4], 
 int zk_parse_fasta(const char* buf, uint64_t len, int final, uint64_t state[4], uint8_t* out, uint64_t out_cap,
                    uint64_t* out_len, uint64_t* consumed);
 
+/* FASTQ text on the device -> base stream of the same length (file.readFastq, library/file.py:38-52):
+ * every byte that is not on the second line of a group of four becomes '\n'.  line_phase = number of
+ * complete lines before this text, mod 4 (feed whole lines); *n_newlines = '\n' bytes in the text.
+ * d_stream may not alias d_text; both 16-byte aligned. */
+int zk_fastq_mask(zk_ctx* ctx, const uint8_t* d_text, uint64_t n, uint32_t line_phase, uint8_t* d_stream, uint64_t* n_newlines);
+
 /* ---- synthetic input (bench / tests) ------------------------------------- */
 
 /* Reads first .. first+count-1 of the counter-based generator (zotmer_amd/synth.py) as a base

@@ -24,7 +24,9 @@ Options:
 # Drop-in for zotmer/commands/kmerize.py (reference file:line cited per step below).  The per-read
 # Python loop, KmerAccumulator2, the spill files and mergeNinto are replaced by device batches:
 # zk_kmerize (encode + radix sort + run-length count + strand mirror) and zk_union_sum.
+import os
 import sys
+import time
 
 import numpy as np
 
@@ -68,9 +70,29 @@ def main(argv):
     table = engine.KmerTable(ctx, K, subsample=subsample, baits=baits)
     batch = engine.batch_bytes_for(ctx, (int(opts["-m"]) << 20) if opts["-m"] is not None else None)
     n_reads = 0
-    for stream, recs in seqio.base_stream_batches(inputs, batch_bytes=batch):
-        table.add_stream(stream)
-        n_reads += recs                             # kmerize.py:527: every record counts
+    timing = os.environ.get("ZOT_TIMING") == "1"
+    t_parse = t_gpu = 0.0
+    t0 = time.perf_counter()
+    for path in inputs:                             # files are simply processed in sequence (reads.py:66-93)
+        if seqio.is_fasta(path):
+            # FASTA records span lines and must be joined: host chunk parser, then upload
+            for stream, recs in seqio.base_stream_batches([path], batch_bytes=batch):
+                t1 = time.perf_counter()
+                t_parse += t1 - t0
+                table.add_stream(stream)
+                t0 = time.perf_counter()
+                t_gpu += t0 - t1
+                n_reads += recs                     # kmerize.py:527: every record counts
+        else:
+            # FASTQ: the text goes to the GPU as it is and is parsed there (zk_fastq_mask); the masked
+            # stream is about twice as long as the bases alone, so batches are half as many reads
+            for text, phase, recs in seqio.fastq_text_batches(path, batch_bytes=batch):
+                t1 = time.perf_counter()
+                t_parse += t1 - t0
+                table.add_fastq_text(text, phase)
+                t0 = time.perf_counter()
+                t_gpu += t0 - t1
+                n_reads += recs
         if verbose:
             sys.stderr.write("\r%d reads" % n_reads)
     if verbose:
@@ -86,6 +108,9 @@ def main(argv):
         z.meta["hist"] = hist
         z.meta["acgt"] = [c / total for c in table.acgt]    # ZeroDivisionError on empty input, as the reference
         z.meta["reads"] = n_reads
+    if timing:
+        sys.stderr.write("zot kmerize: read+parse %.2f s, upload+count %.2f s, hist+encode+write %.2f s\n"
+                         % (t_parse, t_gpu, time.perf_counter() - t0))
 
 
 if __name__ == "__main__":

@@ -253,6 +253,12 @@ int zk_codec64_decode_dev(zk_ctx* c, const uint64_t* d_words, uint64_t nw, int d
     return codec_decode(c, (const u64*)d_words, nw, delta, (u64*)d_out, cap, n_out);
 }
 
+int zk_fastq_mask(zk_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t line_phase, uint8_t* d_stream, uint64_t* n_newlines) {
+    ZK_ARGS(c, n_newlines && d_stream);
+    arena_reset(c);
+    return fastq_mask(c, d_text, n, line_phase, d_stream, n_newlines);
+}
+
 int zk_lower_bound(zk_ctx* c, const uint64_t* d_sorted, uint64_t n, const uint64_t* queries, uint32_t m, uint64_t* positions) {
     ZK_ARGS(c, (m == 0) || (queries && positions));
     if (m == 0) return ZK_OK;

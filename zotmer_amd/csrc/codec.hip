@@ -322,4 +322,69 @@ int codec_encode(zk_ctx* c, const u64* d_vals, uint64_t n, int delta, u64* d_wor
     return check_device_error(c);
 }
 
+// ---------------------------------------------------------------------------------------
+// f2: FASTQ text -> base stream on the device.  file.readFastq (zotmer/library/file.py:38-52) takes
+// lines in groups of four and keeps the second; here every byte learns the number of its line (count
+// of '\n' before it: per-thread popcount, block scan, look-back over the tiles) and every byte that is
+// not on a sequence line becomes '\n'.  The stream keeps the text's length -- header, '+' and quality
+// lines turn into separator runs, which the encode kernels skip like any other non-base byte (quality
+// strings MUST go: they contain the letters A C G T) -- so nothing is compacted or copied on the host.
+// ---------------------------------------------------------------------------------------
+constexpr int FQ_BYTES = 16;                        // bytes per thread
+constexpr int FQ_TILE = CD_BLOCK * FQ_BYTES;
+
+__global__ __launch_bounds__(CD_BLOCK) void fastq_mask_kernel(const u8* __restrict__ text, u64 n, u32 phase0, u8* __restrict__ out,
+                                                              CdState st) {
+    __shared__ CdSmem sm;
+    const u32 tile = take_ticket(st.ticket, &sm.ticket) - st.ticket_base;
+    const u64 base = (u64)tile * FQ_TILE + (u64)threadIdx.x * FQ_BYTES;
+    u8 b[FQ_BYTES];
+    if (base + FQ_BYTES <= n) {
+        const uint4 q = *reinterpret_cast<const uint4*>(text + base);
+        const u32 w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < FQ_BYTES; i++) b[i] = (u8)(w[i >> 2] >> (8 * (i & 3)));
+    } else {
+#pragma unroll
+        for (int i = 0; i < FQ_BYTES; i++) b[i] = (base + i < n) ? text[base + i] : (u8)0;
+    }
+    u32 nl = 0;
+#pragma unroll
+    for (int i = 0; i < FQ_BYTES; i++) nl += (base + i < n && b[i] == '\n') ? 1u : 0u;
+    u64 tile_total;
+    u64 line = (u64)phase0 + blocked_offsets(sm, st, tile, nl, &tile_total);      // line number of my first byte
+    u8 o[FQ_BYTES];
+#pragma unroll
+    for (int i = 0; i < FQ_BYTES; i++) {
+        const bool is_nl = b[i] == '\n';
+        o[i] = ((line & 3) == 1 && !is_nl) ? b[i] : (u8)'\n';
+        line += is_nl ? 1 : 0;
+    }
+    if (base + FQ_BYTES <= n) {
+        u32 w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < FQ_BYTES; i++) w[i >> 2] |= (u32)o[i] << (8 * (i & 3));
+        *reinterpret_cast<uint4*>(out + base) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < FQ_BYTES; i++) if (base + i < n) out[base + i] = o[i];
+    }
+}
+
+int fastq_mask(zk_ctx* c, const u8* d_text, uint64_t n, uint32_t line_phase, u8* d_out, uint64_t* n_newlines) {
+    *n_newlines = 0;
+    if (n == 0) return ZK_OK;
+    if (((uintptr_t)d_text & 15) || ((uintptr_t)d_out & 15)) return fail(c, ZK_EINVAL, "text buffers must be 16-byte aligned");
+    CdState st;
+    st.tiles = (u32)div_up(n, FQ_TILE);
+    ZK_TRY(lookback_begin(c, st.tiles, st.tiles, &st.epoch, &st.ticket_base));
+    st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9;
+    hipLaunchKernelGGL(fastq_mask_kernel, dim3(st.tiles), dim3(CD_BLOCK), 0, c->stream, d_text, (u64)n, line_phase & 3u, d_out, st);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, c->d_scalars + 9, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    *n_newlines = c->h_scalars[9];
+    return check_device_error(c);
+}
+
 }  // namespace zk

@@ -109,6 +109,7 @@ int count_hist(zk_ctx* c, const void* counts, int count_bits, uint64_t n, uint64
                uint64_t cap_bins, uint64_t* n_bins);
 // codec.hip
 int codec_decode(zk_ctx* c, const u64* d_words, uint64_t nw, int delta, u64* d_out, uint64_t cap, uint64_t* n_out);
+int fastq_mask(zk_ctx* c, const u8* d_text, uint64_t n, uint32_t line_phase, u8* d_out, uint64_t* n_newlines);
 int codec_encode(zk_ctx* c, const u64* d_vals, uint64_t n, int delta, u64* d_words, uint64_t cap, uint64_t* n_words);
 // setops.hip
 int union_sum(zk_ctx* c, const u64* A, const void* cA, u64 nA, const u64* B, const void* cB, u64 nB, u64* ok, void* oc,

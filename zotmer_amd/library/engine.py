@@ -57,10 +57,21 @@ class KmerTable:
         self.acgt = [0, 0, 0, 0]
         self.instances = 0
 
+    def add_fastq_text(self, text, line_phase):
+        """Count one batch of raw FASTQ text (whole lines): parsed on the device (zk_fastq_mask)."""
+        d = self.ctx.upload_stream(text)
+        if d.n == 0:
+            return
+        stream, _ = self.ctx.fastq_mask(d, line_phase)
+        del d
+        self.add_device_stream(stream)
+
     def add_stream(self, stream_host):
         """Count one batch (uint8 base stream on the host) into the table."""
+        self.add_device_stream(self.ctx.upload_stream(stream_host))
+
+    def add_device_stream(self, d):
         ctx = self.ctx
-        d = ctx.upload_stream(stream_host)
         if d.n == 0:
             return
         if self.baits is not None:

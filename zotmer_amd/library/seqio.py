@@ -100,3 +100,38 @@ def fasta_sequences(path):
     for stream, _ in base_stream_batches([path]):
         seqs.extend(bytes(stream).split(b"\n")[:-1])
     return seqs
+
+
+def fastq_text_batches(path, batch_bytes=1 << 30):
+    """Raw FASTQ text in batches that end at line ends, for the device-side parser (zk_fastq_mask):
+    yields (bytes, line phase at the start of the batch, records completed inside the batch).  A trailing
+    group of fewer than four lines is dropped, as file.readFastq does (library/file.py:51-52)."""
+    lines = 0
+    carry = b""
+    with open_binary(path) as f:
+        while True:
+            data = f.read(batch_bytes)
+            last = len(data) < batch_bytes
+            buf = carry + data
+            if not last:
+                cut = buf.rfind(b"\n") + 1
+                if cut == 0:                      # no line end at all in this much text: keep reading
+                    carry = buf
+                    continue
+                carry, buf = buf[cut:], buf[:cut]
+            else:
+                carry = b""
+                if buf and not buf.endswith(b"\n"):
+                    buf += b"\n"                  # the last line counts even without a terminator
+            nl = buf.count(b"\n")
+            if last:
+                extra = (lines + nl) % 4          # lines of an incomplete final record
+                for _ in range(extra):
+                    buf = buf[:buf.rfind(b"\n", 0, len(buf) - 1) + 1]
+                nl -= extra
+            if buf:
+                before = lines // 4
+                yield buf, lines % 4, (lines + nl) // 4 - before
+                lines += nl
+            if last:
+                return

@@ -79,6 +79,7 @@ SIGNATURES = {
     "zk_codec64_decode": (_i, [_vp, _u64, _i, _vp, _u64, _pu64]),
     "zk_codec64_encode_dev": (_i, [_vp, _vp, _u64, _i, _vp, _u64, _pu64]),
     "zk_codec64_decode_dev": (_i, [_vp, _vp, _u64, _i, _vp, _u64, _pu64]),
+    "zk_fastq_mask": (_i, [_vp, _vp, _u64, _u32, _vp, _pu64]),
     "zk_parse_fastq": (_i, [_vp, _u64, _i, _pu64, _vp, _u64, _pu64, _pu64]),
     "zk_parse_fasta": (_i, [_vp, _u64, _i, _pu64, _vp, _u64, _pu64, _pu64]),
     "zk_synth_reads": (_i, [_vp, _u64, _u64, _u64, _i, _u64, _u32, _u32, _vp]),
@@ -362,6 +363,13 @@ class Context:
         out = self.empty(n_values, np.uint64)
         self._check(self.lib.zk_codec64_decode_dev(self.h, words.ptr, words.n, int(delta), out.ptr, int(n_values), C.byref(n)))
         return out.view(n.value)
+
+    def fastq_mask(self, text, line_phase=0):
+        """FASTQ text on the device -> (base stream of the same length, number of newlines)."""
+        out = self.empty(text.n, np.uint8)
+        n = C.c_uint64(0)
+        self._check(self.lib.zk_fastq_mask(self.h, text.ptr, text.n, int(line_phase) & 3, out.ptr, C.byref(n)))
+        return out, n.value
 
     def lower_bound(self, sorted_keys, queries):
         q = np.ascontiguousarray(queries, dtype=np.uint64)
