@@ -7,7 +7,7 @@ from zotmer_amd import native
 
 def main():
     n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1 << 30
-    variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3, 4, 5, 6]
+    variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2, 3]
     ctx = native.Context(0)
     # 50-bit pseudo-random keys generated on device: reuse the synth generator bytes as entropy
     rng = np.random.default_rng(1)

@@ -9,7 +9,7 @@ from zotmer_amd import native
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1 << 28
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-tile = {0: 8192, 3: 8192, 4: 8192, 5: 8192, 1: 4096, 6: 4096, 2: 16384, 7: 16384}[variant]
+tile = {0: 8192, 3: 8192, 1: 4096, 2: 16384}[variant]
 ctx = native.Context(0)
 ctx.tune(sort_variant=variant)
 rng = np.random.default_rng(1)

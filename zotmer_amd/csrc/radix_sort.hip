@@ -32,11 +32,9 @@ constexpr int MAX_RADIX = 1024;
 
 enum { SRC_ARRAY = 0, SRC_STREAM = 1 };
 
-// LB_: 0 = publish the tile's digit counts after the ranking; 4 = count with LDS atomics first,
-//          publish, then rank (the ranking overlaps the successors' look-back).
-template <int BLOCK_, int ITEMS_, int RBITS_, int LB_ = 0>
+template <int BLOCK_, int ITEMS_, int RBITS_>
 struct Cfg {
-    static constexpr int BLOCK = BLOCK_, ITEMS = ITEMS_, RBITS = RBITS_, LB = LB_;
+    static constexpr int BLOCK = BLOCK_, ITEMS = ITEMS_, RBITS = RBITS_;
     static constexpr int TILE = BLOCK * ITEMS, RADIX = 1 << RBITS, NW = BLOCK / 64;
     static constexpr int DPT = (RADIX + BLOCK - 1) / BLOCK;   // digits per thread in the per-digit steps
     static_assert(ITEMS % 2 == 0 && 2 * ITEMS < 256, "ITEMS");
@@ -190,9 +188,12 @@ __global__ __launch_bounds__(C::BLOCK) void hist_kernel(HistArgs h) {
 #pragma unroll
         for (int i = 0; i < C::ITEMS; i++) {
             if ((live >> i) & 1u) {
-                for (int p = 0; p < h.plan.passes; p++) {
-                    u32 d = (u32)(key[i] >> h.plan.shift[p]) & ((1u << h.plan.bits[p]) - 1u);
-                    atomicAdd(&bins[p * C::RADIX + d], 1u);
+#pragma unroll
+                for (int p = 0; p < MAX_PASSES; p++) {
+                    if (p < h.plan.passes) {
+                        const u32 d = (u32)(key[i] >> h.plan.shift[p]) & ((1u << h.plan.bits[p]) - 1u);
+                        atomicAdd(&bins[p * C::RADIX + d], 1u);
+                    }
                 }
             }
         }
@@ -256,7 +257,6 @@ struct PassSmem {
         TileImage<C::TILE> img;
     };
     u16 cnt[C::NW][C::RADIX];
-    u32 hist[C::LB == 4 ? C::RADIX : 1];   // early tile histogram (LB 4 only)
     u32 digit_off[C::RADIX];
     u64 gbase[C::RADIX];
     u32 wsum[C::NW];
@@ -299,8 +299,6 @@ __global__ __launch_bounds__(C::BLOCK) void pass_kernel(SortArgs a) {
 
     u16* mycnt = sm.cnt[wave];
     for (int d = lane; d < RADIX; d += 64) mycnt[d] = 0;
-    if (C::LB == 4)
-        for (int d = tid; d < RADIX; d += BLOCK) sm.hist[d] = 0;
     __syncthreads();
 #ifdef ZK_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -310,35 +308,6 @@ __global__ __launch_bounds__(C::BLOCK) void pass_kernel(SortArgs a) {
     // thread t owns digits t*DPT .. t*DPT+DPT-1 in the per-digit steps
     u32 tcount[DPT];
     u32 dig_excl = 0;
-
-    if (C::LB == 4) {
-        // ---- early publish ----------------------------------------------------------------------
-        // Measured with in-kernel stamps: with the publish after the ranking, a tile spent 40 % of
-        // its life in the look-back, almost all of it waiting for predecessors that were still
-        // ranking (workgroups reach that point with microseconds of jitter).  The digit COUNTS need
-        // no ranking, only a histogram (LDS atomics, a fraction of the ranking's cost).  So: count,
-        // publish, rank -- the ranking of every tile now overlaps its successors' waiting.
-#pragma unroll
-        for (int i = 0; i < ITEMS; i++)
-            if ((live >> i) & 1u) atomicAdd(&sm.hist[(u32)(key[i] >> a.shift) & dmask], 1u);
-        __syncthreads();
-        u32 tsum = 0;
-#pragma unroll
-        for (int j = 0; j < DPT; j++) {
-            const int d = tid * DPT + j;
-            tcount[j] = (d < RADIX) ? sm.hist[d] : 0u;
-            tsum += tcount[j];
-            if (d < RADIX)
-                st_agent(a.status + (u64)tile * RADIX + d, st_pack(tile == 0 ? ZK_ST_INCLUSIVE : ZK_ST_PARTIAL, a.epoch, tcount[j]));
-        }
-        const u32 inc = wave_incl_scan_u32(tsum);
-        if (lane == 63) sm.wsum[wave] = inc;
-        __syncthreads();
-        u32 woff = 0;
-        for (int w = 0; w < wave; w++) woff += sm.wsum[w];
-        dig_excl = woff + inc - tsum;
-        if (tid == BLOCK - 1) sm.total_live = woff + inc;
-    }
 
     // ---- rank inside the wave ------------------------------------------------------------
     u32 rank[ITEMS];
@@ -382,19 +351,17 @@ __global__ __launch_bounds__(C::BLOCK) void pass_kernel(SortArgs a) {
                 acc += t;
             }
         }
-        if (C::LB != 4) tcount[j] = acc;
+        tcount[j] = acc;
         tsum2 += acc;
     }
-    if (C::LB != 4) {
-        // exclusive scan over the digits
-        const u32 inc = wave_incl_scan_u32(tsum2);
-        if (lane == 63) sm.wsum[wave] = inc;
-        __syncthreads();
-        u32 woff = 0;
-        for (int w = 0; w < wave; w++) woff += sm.wsum[w];
-        dig_excl = woff + inc - tsum2;
-        if (tid == BLOCK - 1) sm.total_live = woff + inc;
-    }
+    // exclusive scan over the digits
+    const u32 inc = wave_incl_scan_u32(tsum2);
+    if (lane == 63) sm.wsum[wave] = inc;
+    __syncthreads();
+    u32 woff = 0;
+    for (int w = 0; w < wave; w++) woff += sm.wsum[w];
+    dig_excl = woff + inc - tsum2;
+    if (tid == BLOCK - 1) sm.total_live = woff + inc;
 
     // ---- decoupled look-back, one chain per digit ----------------------------------------------
     ZK_STAMP(4);
@@ -405,9 +372,9 @@ __global__ __launch_bounds__(C::BLOCK) void pass_kernel(SortArgs a) {
             u64* st = a.status + (u64)tile * RADIX + d;
             u64 excl = 0;
             if (tile == 0) {
-                if (C::LB != 4) st_agent(st, st_pack(ZK_ST_INCLUSIVE, a.epoch, tcount[j]));
+                st_agent(st, st_pack(ZK_ST_INCLUSIVE, a.epoch, tcount[j]));
             } else {
-                if (C::LB != 4) st_agent(st, st_pack(ZK_ST_PARTIAL, a.epoch, tcount[j]));
+                st_agent(st, st_pack(ZK_ST_PARTIAL, a.epoch, tcount[j]));
 #ifdef ZK_NO_LOOKBACK   /* timing experiment only: results are wrong */
                 {   // stay inside the digit's bin so every store is in range
                     const u64 lo = a.ghist[d], hi = (d + 1 < RADIX) ? a.ghist[d + 1] : a.n;
@@ -592,26 +559,20 @@ struct Sorter {
     }
 };
 
-// the instantiated geometries; index = zk_tune(ZK_TUNE_SORT_VARIANT / ZK_TUNE_PAIRS_VARIANT)
-typedef Cfg<512, 16, 8, 0> V0;
-typedef Cfg<256, 16, 8, 0> V1;
-typedef Cfg<1024, 16, 8, 0> V2;
-typedef Cfg<512, 16, 9, 0> V3;
-typedef Cfg<512, 16, 8, 4> V4;
-typedef Cfg<512, 16, 9, 4> V5;
-typedef Cfg<256, 16, 8, 4> V6;
-typedef Cfg<1024, 16, 8, 4> V7;
+// the instantiated geometries; index = zk_tune(ZK_TUNE_SORT_VARIANT / ZK_TUNE_PAIRS_VARIANT).
+// Measured on MI355X (tools/sortbench.py, 2^30 50-bit keys): 0 -> 3.1 TB/s x 7 passes, 1 -> 2.4,
+// 2 -> 2.9, 3 -> 2.75 x 6 passes (the fastest total).
+typedef Cfg<512, 16, 8> V0;
+typedef Cfg<256, 16, 8> V1;
+typedef Cfg<1024, 16, 8> V2;
+typedef Cfg<512, 16, 9> V3;
 #define ZK_SORT_DISPATCH(c, CALL) ZK_SORT_DISPATCH_V((c)->sort_variant, CALL)
 #define ZK_SORT_DISPATCH_V(v, CALL)                 \
     switch (v) {                                    \
+        case 0: return Sorter<V0>::CALL;            \
         case 1: return Sorter<V1>::CALL;            \
         case 2: return Sorter<V2>::CALL;            \
-        case 3: return Sorter<V3>::CALL;            \
-        case 4: return Sorter<V4>::CALL;            \
-        case 5: return Sorter<V5>::CALL;            \
-        case 6: return Sorter<V6>::CALL;            \
-        case 7: return Sorter<V7>::CALL;            \
-        default: return Sorter<V0>::CALL;           \
+        default: return Sorter<V3>::CALL;           \
     }
 
 int sort_keys(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** result) {
@@ -628,7 +589,7 @@ int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n,
 
 // digit width of the geometry used for key arrays (the truncated sort sizes its bit range with it)
 int sort_rbits(zk_ctx* c) {
-    switch (c->sort_variant) { case 3: case 5: return 9; default: return 8; }
+    switch (c->sort_variant) { case 0: case 1: case 2: return 8; default: return 9; }
 }
 
 int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,
