@@ -212,7 +212,7 @@ def main():
                        "parallelism": "1 gpu" if world == 1 else "reads sharded over %d gpus + value-range all-to-all" % world},
             "roofline": {"bound": "hbm", "kernel": "pass_kernel<array,keys> (one LSD radix pass, 16 B/key)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("pass_kernel<zk::Cfg<512, 16, 9, 0>, 0, false>", st.n_windows),
+                         "traffic": measured_traffic("pass_kernel<zk::Cfg<512, 16, 9>, 0, false>", st.n_windows),
                          "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, KiB) of this "
                                          "command, profiles/r01_config2_final/pmc_traffic.json; null if the workload differs",
                          "launches": pk["launches"],
