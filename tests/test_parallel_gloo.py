@@ -86,6 +86,45 @@ def _worker(rank, world, port, outdir):
         dist.destroy_process_group()
 
 
+def _merge_dist_worker(rank, world, port, outdir):
+    """`zot merge` and `zot dist` over `world` ranks: rank r owns sets r, r+world, ... (64-bit counts)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ops = NumpyOps()
+        ex = parallel.RangeExchange(None, dist, K, ops=ops)
+        mine = [zo.kmerize(K, _reads(s)) for s in range(rank, 6, world)]
+        k = np.empty(0, np.uint64); c = np.empty(0, np.uint64)
+        for t in mine:                                     # local k-way merge of this rank's sets
+            k, c = zo.union_sum(k, c, t["kmers"], t["counts"].astype(np.uint64))
+        kt = torch.from_numpy(k.view(np.int64).copy()); ct = torch.from_numpy(c.view(np.int64).copy())
+        rk, rc, segs = ex.exchange(kt, ct, len(k))
+        mk = np.empty(0, np.uint64); mc = np.empty(0, np.uint64)
+        for o, n in segs:
+            mk, mc = zo.union_sum(mk, mc, rk[o:o + n].numpy().view(np.uint64), rc[o:o + n].numpy().view(np.uint64))
+        # dist: every rank holds both sets in full and splits only its value range
+        a = zo.kmerize(K, _reads(0))["kmers"]; b = zo.kmerize(K, _reads(1))["kmers"]
+        at = torch.from_numpy(a.view(np.int64).copy()); bt = torch.from_numpy(b.view(np.int64).copy())
+        a0, a1 = ex.owned_slice(at, len(a)); b0, b1 = ex.owned_slice(bt, len(b))
+        abc = ex.split_counts(zo.split(a[a0:a1], b[b0:b1]))
+        np.savez(os.path.join(outdir, "m%d.npz" % rank), k=mk, c=mc, abc=np.array(abc))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_distributed_merge_and_dist_gloo(tmp_path, world):
+    mp.spawn(_merge_dist_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(str(tmp_path / ("m%d.npz" % r))) for r in range(world)]
+    zs, zc, _ = zo.merge_n(K, [(t["kmers"], t["counts"].astype(np.uint64)) for t in (zo.kmerize(K, _reads(s)) for s in range(6))])
+    assert np.array_equal(np.concatenate([p["k"] for p in parts]), zs)
+    assert np.array_equal(np.concatenate([p["c"] for p in parts]), zc)
+    want = zo.split(zo.kmerize(K, _reads(0))["kmers"], zo.kmerize(K, _reads(1))["kmers"])
+    for p in parts:
+        assert tuple(p["abc"]) == want
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -16,6 +16,10 @@ same splitters, zk_split locally, all-reduce three integers (`split_counts`).
 The arithmetic on the data path is injected (`ops`), so the protocol -- split sizes, the two
 all-to-all rounds, merge order, the checksum reduction -- runs unchanged under the "gloo" backend on
 CPU tensors in the tests.
+
+`zot merge` over N GPUs = the same exchange: every rank merges the sets it loaded (zk_merge_n), the
+result is range-partitioned and exchanged, and the received pieces are merged again; the global set
+is the concatenation of the ranks' pieces in rank order.
 """
 import numpy as np
 import torch
@@ -43,6 +47,8 @@ class GpuOps:
         return self._borrow(self.ctx, t.data_ptr() + 8 * off, np.uint64, n, keep=t)
 
     def c_array(self, t, n, off=0):
+        if t.dtype == torch.int64:       # uint64 counts (merge) travel as int64, uint32 counts (kmerize) as int32
+            return self._borrow(self.ctx, t.data_ptr() + 8 * off, np.uint64, n, keep=t)
         return self._borrow(self.ctx, t.data_ptr() + 4 * off, np.uint32, n, keep=t)
 
     def lower_bound(self, keys_t, n, cuts):
@@ -64,10 +70,11 @@ class GpuOps:
         if len(parts) == 1:
             return parts[0]
         total = sum(p[0].n for p in parts)
-        if getattr(self, "_mk", None) is None or self._mk.n < total:
+        cdt = parts[0][1].dtype
+        if getattr(self, "_mk", None) is None or self._mk.n < total or self._mc.dtype != cdt:
             self._mk = self._mc = None
             self._mk = self.ctx.empty(total + total // 16, np.uint64)
-            self._mc = self.ctx.empty(total + total // 16, np.uint32)
+            self._mc = self.ctx.empty(total + total // 16, cdt)
         k, c, _ = self.ctx.merge_n(parts, out=(self._mk, self._mc))
         return k, c
 
@@ -95,10 +102,10 @@ class RangeExchange:
         dist.all_to_all_single(r, s)
         recv = [int(v) for v in r.tolist()]
         total = sum(recv)
-        if self._rk is None or self._rk.numel() < total:
+        if self._rk is None or self._rk.numel() < total or self._rc.dtype != counts_t.dtype:
             self._rk = self._rc = None
             self._rk = ops.empty(total + total // 16, torch.int64)
-            self._rc = ops.empty(total + total // 16, torch.int32)
+            self._rc = ops.empty(total + total // 16, counts_t.dtype)
         rk, rc = self._rk, self._rc
         dist.all_to_all_single(rk[:total], keys_t[:n], recv, send)
         dist.all_to_all_single(rc[:total], counts_t[:n], recv, send)
@@ -128,6 +135,13 @@ class RangeExchange:
         def join(lo, hi):
             return [(l + (h << 32)) & 0xFFFFFFFFFFFFFFFF for l, h in zip(lo, hi)]
         return join(v[0:3], v[3:6]) == join(v[6:9], v[9:12])
+
+    def owned_slice(self, keys_t, n):
+        """(start, end) of this rank's value range inside a sorted array every rank holds in full --
+        how `zot dist` shards: both sets are cut with the same splitters, each rank runs zk_split on its
+        slices, and split_counts() adds the three integers up."""
+        pos = [0] + self.ops.lower_bound(keys_t, n, self.cuts) + [n]
+        return pos[self.rank], pos[self.rank + 1]
 
     def split_counts(self, abc_local):
         """dist: all-reduce the (a, b, c) of the rank's key range."""
