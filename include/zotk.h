@@ -177,6 +177,16 @@ int zk_split(zk_ctx* ctx, const uint64_t* d_x, uint64_t nx, const uint64_t* d_y,
  * entries): the cut points of a value-range partition for the multi-GPU exchange. */
 int zk_lower_bound(zk_ctx* ctx, const uint64_t* d_sorted, uint64_t n, const uint64_t* queries, uint32_t m, uint64_t* positions);
 
+/* ---- next-row commands on the same kernels ---------------------------------------- */
+
+/* project.project2 (commands/project.py:29-40): the (k-mer, count) entries of a set whose k-mer is in the
+ * sorted reference set; 64-bit counts. */
+int zk_project(zk_ctx* ctx, const uint64_t* d_ref, uint64_t n_ref, const uint64_t* d_kmers, const uint64_t* d_counts, uint64_t n,
+               uint64_t* d_ok, uint64_t* d_oc, uint64_t cap, uint64_t* n_out);
+/* sample.sampleD (commands/sample.py:27-34): keep iff float(murmer(x, seed) & (2^40 - 1)) / float(2^40 - 1) < p. */
+int zk_sample(zk_ctx* ctx, const uint64_t* d_kmers, const uint64_t* d_counts, uint64_t n, uint64_t seed, double p,
+              uint64_t* d_ok, uint64_t* d_oc, uint64_t cap, uint64_t* n_out);
+
 /* ---- K10: trim ---------------------------------------------------------------------------------- */
 
 /* trim.trim (commands/trim.py:54-62): keep (x, f) iff f >= lo and (hi == 0 or f <= hi). */

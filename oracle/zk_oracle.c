@@ -431,6 +431,33 @@ void zo_split(const u64* xs, u64 nx, const u64* ys, u64 ny, u64 abc[3]) {
 }
 
 /* ------------------------------------------------------------------------------------------
+ * next-row commands on the same sets: zot project, zot sample
+ * ---------------------------------------------------------------------------------------- */
+
+/* project.project2 (zotmer/commands/project.py:29-40): the entries (y, c) of the input whose k-mer is
+ * in the sorted reference xs. */
+u64 zo_project(const u64* xs, u64 nx, const u64* ys, const u64* yc, u64 ny, u64* ok, u64* oc) {
+    u64 i = 0, m = 0;
+    for (u64 j = 0; j < ny; j++) {
+        while (i < nx && xs[i] < ys[j]) i++;
+        if (i == nx) break;
+        if (xs[i] == ys[j]) { ok[m] = ys[j]; oc[m] = yc[j]; m++; i++; }
+    }
+    return m;
+}
+
+/* sample.sampleD (zotmer/commands/sample.py:27-34): keep iff float(murmer(y, s) & (2^40 - 1)) / float(2^40 - 1) < p */
+u64 zo_sample_d(double p, u64 seed, const u64* ys, const u64* yc, u64 ny, u64* ok, u64* oc) {
+    const u64 M = 0xFFFFFFFFFFULL;
+    u64 m = 0;
+    for (u64 j = 0; j < ny; j++) {
+        double u = (double)(zo_murmer(ys[j], seed) & M) / (double)M;
+        if (u < p) { ok[m] = ys[j]; oc[m] = yc[j]; m++; }
+    }
+    return m;
+}
+
+/* ------------------------------------------------------------------------------------------
  * zot trim: zotmer/commands/trim.py
  * ---------------------------------------------------------------------------------------- */
 

@@ -75,6 +75,10 @@ def lib():
         L.zo_split.restype = None; L.zo_split.argtypes = [u64p, C.c_uint64, u64p, C.c_uint64, u64p]
         L.zo_trim.restype = C.c_uint64
         L.zo_trim.argtypes = [u64p, u64p, C.c_uint64, C.c_uint64, C.c_uint64, u64p, u64p]
+        L.zo_project.restype = C.c_uint64
+        L.zo_project.argtypes = [u64p, C.c_uint64, u64p, u64p, C.c_uint64, u64p, u64p]
+        L.zo_sample_d.restype = C.c_uint64
+        L.zo_sample_d.argtypes = [C.c_double, C.c_uint64, u64p, u64p, C.c_uint64, u64p, u64p]
         L.zo_codec64_encode.restype = C.c_int64; L.zo_codec64_encode.argtypes = [u64p, C.c_uint64, u64p]
         L.zo_codec64_decode.restype = C.c_int64; L.zo_codec64_decode.argtypes = [u64p, C.c_uint64, u64p]
         L.zo_delta.restype = None; L.zo_delta.argtypes = [u64p, C.c_uint64, u64p]
@@ -229,6 +233,82 @@ def trim(xs, cs, lo, hi=0):
     oc = np.empty(max(len(xs), 1), dtype=np.uint64)
     m = lib().zo_trim(_p64(xs), _p64(cs), len(xs), lo, hi, _p64(ox), _p64(oc))
     return ox[:m].copy(), oc[:m].copy()
+
+
+def project(xs, ys, yc):
+    xs, ys, yc = _a64(xs), _a64(ys), _a64(yc)
+    ok = np.empty(max(len(ys), 1), dtype=np.uint64); oc = np.empty(max(len(ys), 1), dtype=np.uint64)
+    m = lib().zo_project(_p64(xs), len(xs), _p64(ys), _p64(yc), len(ys), _p64(ok), _p64(oc))
+    return ok[:m].copy(), oc[:m].copy()
+
+
+def sample_d(p, seed, ys, yc):
+    ys, yc = _a64(ys), _a64(yc)
+    ok = np.empty(max(len(ys), 1), dtype=np.uint64); oc = np.empty(max(len(ys), 1), dtype=np.uint64)
+    m = lib().zo_sample_d(float(p), int(seed), _p64(ys), _p64(yc), len(ys), _p64(ok), _p64(oc))
+    return ok[:m].copy(), oc[:m].copy()
+
+
+# ---- zot jaccard statistics: zotmer/commands/jaccard.py:56-88, zotmer/library/stats.py:36-129 ----------
+
+_LOG_SMALL_FAC = [math.log(math.factorial(n)) for n in range(25)]            # stats.py:45
+
+
+def log_fac(n):                                                               # stats.py:77-83
+    if n < len(_LOG_SMALL_FAC):
+        return _LOG_SMALL_FAC[n]
+    return n * math.log(n) - n + math.log(n * (1 + 4 * n * (1 + 2 * n))) / 6.0 + math.log(math.pi) / 2.0
+
+
+def log_choose(n, k):                                                         # stats.py:121-128
+    if k == 0 or k == n:
+        return 0
+    return log_fac(n) - (log_fac(n - k) + log_fac(k))
+
+
+def log_add(a, b):                                                            # stats.py:85-92
+    x, y = max(a, b), min(a, b)
+    return x + math.log1p(math.exp(y - x))
+
+
+def log_ix(x, m, n):                                                          # jaccard.py:56-71
+    lx = math.log(x)
+    j = m
+    v = log_choose(n + j - 1, j)
+    s = v + j * lx
+    while True:
+        j += 1
+        v += math.log((n + j - 1.0) / j)
+        t = v + j * lx
+        u = log_add(s, t)
+        if u == s:
+            break
+        s = u
+    return n * math.log1p(-x) + s
+
+
+def quant_beta(q, m, n):                                                      # jaccard.py:73-84
+    lq = math.log(q)
+    lo, hi = 1e-10, 1 - 1e-10
+    while (hi - lo) > 1e-7:
+        x = (hi + lo) / 2.0
+        if log_ix(x, m, n) < lq:
+            lo = x
+        else:
+            hi = x
+    return lo
+
+
+def jaccard_line(xn, yn, nx, ny, isec, p=None):
+    """One output line of zot jaccard (jaccard.py:117-124,142-149)."""
+    union = nx + ny - isec
+    d = float(isec) / float(union)
+    if p is None:
+        return "%s\t%s\t%d\t%d\t%d\t%d\t%f" % (xn, yn, nx, ny, isec, union, d)
+    pv = log_ix(p, isec + 1, (union - isec) + 1) / math.log(10)
+    q05 = quant_beta(0.05, isec + 1, (union - isec) + 1)
+    q95 = quant_beta(0.95, isec + 1, (union - isec) + 1)
+    return "%s\t%s\t%d\t%d\t%d\t%d\t%f\t-%f\t+%f\t%f" % (xn, yn, nx, ny, isec, union, d, d - q05, q95 - d, pv)
 
 
 def codec64_encode(xs):

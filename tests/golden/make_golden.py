@@ -155,9 +155,9 @@ def build_derived():
     shutil.copytree(REF + "/zotmer", WORK + "/zotmer")
     subprocess.check_call(["chmod", "-R", "u+w", WORK])
     files = [WORK + "/zotmer/library/%s.py" % m for m in
-             ("basics", "bits", "misc", "codec64", "files", "file", "kmers", "reads", "dist", "exceptions", "timer")]
+             ("basics", "bits", "misc", "codec64", "files", "file", "kmers", "reads", "dist", "exceptions", "timer", "stats")]
     files += [WORK + "/zotmer/library/container/%s.py" % m for m in ("__init__", "casket", "std", "vectors")]
-    files += [WORK + "/zotmer/commands/%s.py" % m for m in ("kmerize", "merge", "dist", "trim")]
+    files += [WORK + "/zotmer/commands/%s.py" % m for m in ("kmerize", "merge", "dist", "trim", "jaccard", "project", "sample")]
     subprocess.check_call([sys.executable, "-W", "ignore", "-m", "lib2to3", "-w", "-n"] + files,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
@@ -344,6 +344,31 @@ def commands():
     with open(os.path.join(HERE, "g5_dist.json"), "w") as f:
         json.dump(dist, f, indent=1, sort_keys=True)
     print("dist:", {k: (v.get("stdout", "") or "")[:60] for k, v in dist.items() if isinstance(v, dict)})
+
+    # f3: jaccard / project / sample on the same sets
+    f3 = {}
+    o, e = run("jaccard", {"-a": False, "-b": False, "-p": None, "<input>": parts[:3]})
+    f3["jaccard_default"] = dict(inputs=["g4_part0", "g4_part1", "g4_part2"], stdout=o)
+    o, e = run("jaccard", {"-a": True, "-b": False, "-p": None, "<input>": parts[:3]})
+    f3["jaccard_all"] = dict(inputs=["g4_part0", "g4_part1", "g4_part2"], stdout=o)
+    o, e = run("jaccard", {"-a": False, "-b": False, "-p": "0.5", "<input>": parts[:2]})
+    f3["jaccard_p0.5"] = dict(inputs=["g4_part0", "g4_part1"], stdout=o)
+    jfa = ">s1 first\n" + synth.read_strings(synth.DEFAULT_SEED + 1, 0, 1, 150, genome=20000)[0] + "\n" + \
+          ">s2\n" + synth.read_strings(synth.DEFAULT_SEED + 1, 0, 1, 150, genome=20000)[0][20:] + "ACGTTGCA\n" + \
+          ">s3 x\n" + synth.read_strings(synth.DEFAULT_SEED + 1, 7, 1, 150, genome=20000)[0] + "\n"
+    open(W + "j.fa", "w").write(jfa)
+    o, e = run("jaccard", {"-a": True, "-b": False, "-p": None, "<input>": [W + "j.fa"]})
+    f3["jaccard_fasta_all"] = dict(fasta=jfa, stdout=o)
+    with open(os.path.join(HERE, "f3_jaccard.json"), "w") as f:
+        json.dump(f3, f, indent=1, sort_keys=True)
+    run("project", {"<ref>": parts[1], "<output>": W + "prj.k25", "<input>": parts[0]})
+    save_case("f3_project_part0_on_part1", *load_set(W + "prj.k25"), extra=dict(ref="g4_part1", input="g4_part0"))
+    run("sample", {"-D": True, "-S": "5", "-P": "0.3", "<output>": W + "smp.k25", "<input>": parts[0]})
+    save_case("f3_sample_D_S5_P0.3", *load_set(W + "smp.k25"), extra=dict(input="g4_part0", S=5, P=0.3))
+    run("sample", {"-D": False, "-S": None, "-P": None, "<output>": W + "smp2.k25", "<input>": parts[0]})
+    save_case("f3_sample_defaults", *load_set(W + "smp2.k25"), extra=dict(input="g4_part0", S=0, P=0.01,
+              note="docopt gives False (not None) for an absent -D, so commands/sample.py:51 always takes the deterministic branch"))
+    print("f3:", {k: v["stdout"][:70] for k, v in f3.items()})
 
     # config 1 at full size (10 000 x 150 bp genome-sampled): digests only
     c = synth.CONFIGS["config1"]

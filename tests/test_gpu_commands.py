@@ -178,3 +178,61 @@ def test_info_hist_dump(tmp_path):
     assert out == "".join("%s\t%d\n" % (zo.render(25, int(k)), int(c)) for k, c in zip(km, ct))
     _, rc = zot("nosuchcommand")
     assert rc == 1
+
+
+def _retarget(ref, paths):
+    """the reference printed its own temporary paths: map them to ours, in order of appearance"""
+    names = []
+    for row in (l.split("\t") for l in ref.strip().split("\n")):
+        for nm in row[:2]:
+            if nm not in names and "/" in nm:
+                names.append(nm)
+    for old, new in zip(names, paths):
+        ref = ref.replace(old, new)
+    return ref
+
+
+def test_jaccard_stdout(tmp_path):
+    g = G.load_json("f3_jaccard")
+    files = {n: make_set(tmp_path, n) for n in ("g4_part0", "g4_part1", "g4_part2")}
+    for key, flags in (("jaccard_default", []), ("jaccard_all", ["-a"]), ("jaccard_p0.5", ["-p", "0.5"])):
+        paths = [str(files[n]) for n in g[key]["inputs"]]
+        out, _ = zot("jaccard", *(flags + paths))
+        assert out == _retarget(g[key]["stdout"], paths), key
+    fa = tmp_path / "two.fa"
+    fa.write_text(g["jaccard_fasta_all"]["fasta"])
+    out, _ = zot("jaccard", "-a", fa)
+    assert out == g["jaccard_fasta_all"]["stdout"]
+    # mismatched K: message + exit status 1 (jaccard.py:151-153)
+    other = tmp_path / "k24.k24"
+    info, km, ct, _, _ = G.load_case("g3_kmerize_genome_k24")
+    with KmerSet(str(other), "w") as z:
+        vectors.write_kmers_and_counts(z, km, ct)
+        z.meta.update(info["meta"])
+    with pytest.raises(SystemExit) as e:
+        zot("jaccard", files["g4_part0"], other)
+    assert e.value.code == 1
+
+
+def test_project_and_sample_files(tmp_path):
+    p0, p1 = make_set(tmp_path, "g4_part0"), make_set(tmp_path, "g4_part1")
+    out = tmp_path / "proj.k25"
+    zot("project", p1, out, p0)
+    meta = check_file(out, "f3_project_part0_on_part1", meta_keys=("K", "hist"))
+    assert "acgt" not in meta and "reads" not in meta                  # only K and hist travel (project.py:55-66)
+    out = tmp_path / "s1.k25"
+    zot("sample", "-D", "-S", 5, "-P", 0.3, out, p0)
+    check_file(out, "f3_sample_D_S5_P0.3")
+    out = tmp_path / "s2.k25"
+    zot("sample", out, p0)                                             # defaults: P 0.01, seed 0, still hash-based
+    check_file(out, "f3_sample_defaults")
+    # an input without counts projects to an output without counts
+    info, km, ct, _, _ = G.load_case("g4_part0")
+    bare = tmp_path / "bare.k25"
+    with KmerSet(str(bare), "w") as z:
+        z.add("kmers", vectors.encode_kmers(km))
+        z.meta.update({"K": 25, "kmers": "kmers", "hist": {}})
+    out = tmp_path / "proj2.k25"
+    zot("project", p1, out, bare)
+    m = members(out)
+    assert m["kmers"] == G.load_case("f3_project_part0_on_part1")[3] and "counts" not in m

@@ -371,3 +371,45 @@ def test_trim_golden(ctx):
             assert np.array_equal(k.to_host(), tk) and np.array_equal(c.to_host().astype(np.uint64), tc)
     k, c = ctx.trim(dk, ctx.upload(ct), 10 ** 9)
     assert k.n == 0
+
+
+# ---- f3: project / sample -----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("nr,ni", [(0, 0), (0, 1000), (1000, 0), (1, 1), (5000, 77), (77, 5000), (300_000, 1_000_000)])
+def test_project_random_vs_oracle(ctx, nr, ni):
+    rng = np.random.default_rng(7 * nr + ni)
+    pool = np.arange(1, 1 << 21, dtype=np.uint64) * np.uint64(0x2b1)
+    ref = np.sort(rng.choice(pool, size=nr, replace=False)) if nr else np.empty(0, np.uint64)
+    x = np.sort(rng.choice(pool, size=ni, replace=False)) if ni else np.empty(0, np.uint64)
+    c = rng.integers(1, 1 << 40, size=ni, dtype=np.uint64)
+    k, kc = ctx.project(ctx.upload(ref), ctx.upload(x), ctx.upload(c))
+    ek, ec = zo.project(ref, x, c)
+    assert np.array_equal(k.to_host(), ek) and np.array_equal(kc.to_host(), ec)
+    k, kc = ctx.project(ctx.upload(x), ctx.upload(x), ctx.upload(c))          # a set projected on itself is itself
+    assert np.array_equal(k.to_host(), x) and np.array_equal(kc.to_host(), c)
+
+
+def test_project_and_sample_golden(ctx):
+    _, k0, c0, _, _ = G.load_case("g4_part0")
+    _, k1, _, _, _ = G.load_case("g4_part1")
+    _, ek, ec, _, _ = G.load_case("f3_project_part0_on_part1")
+    k, c = ctx.project(ctx.upload(k1), ctx.upload(k0), ctx.upload(c0))
+    assert np.array_equal(k.to_host(), ek) and np.array_equal(c.to_host(), ec)
+    for name in ("f3_sample_D_S5_P0.3", "f3_sample_defaults"):
+        info, ek, ec, _, _ = G.load_case(name)
+        k, c = ctx.sample(ctx.upload(k0), ctx.upload(c0), info["S"], info["P"])
+        assert np.array_equal(k.to_host(), ek) and np.array_equal(c.to_host(), ec)
+
+
+@pytest.mark.parametrize("n,p,seed", [(0, 0.5, 1), (1000, 0.0, 1), (1000, 1.0, 1), (1000, 1.5, 9), (2_000_000, 0.01, 0),
+                                      (2_000_000, 0.37, 2 ** 63 + 11)])
+def test_sample_random_vs_oracle(ctx, n, p, seed):
+    rng = np.random.default_rng(n + seed % 1000)
+    x = np.sort(rng.integers(0, 1 << 50, size=n, dtype=np.uint64))
+    c = rng.integers(1, 1 << 33, size=n, dtype=np.uint64)
+    k, kc = ctx.sample(ctx.upload(x), ctx.upload(c), seed, p)
+    ek, ec = zo.sample_d(p, seed, x, c)
+    assert np.array_equal(k.to_host(), ek) and np.array_equal(kc.to_host(), ec)
+    if p >= 1.0 and n:
+        # u == 1.0 exactly only when all 40 hash bits are set; with p > 1 everything stays
+        assert k.n == n if p > 1.0 else k.n >= n - 1

@@ -214,3 +214,55 @@ def test_config1_digest():
     assert G.hist_dict(r["counts"]) == g["meta"]["hist"]
     tot = float(sum(r["acgt"]))
     assert [c / tot for c in r["acgt"]] == g["meta"]["acgt"]
+
+
+# ---- next-row commands (f3): jaccard / project / sample ------------------------------------------------
+
+def _rename(ref, names_new):
+    """The reference printed its temporary paths; map them to given names in order of appearance."""
+    names = []
+    for row in (l.split("\t") for l in ref.strip().split("\n")):
+        for nm in row[:2]:
+            if nm not in names and "\t" not in nm and "/" in nm:
+                names.append(nm)
+    for old, new in zip(names, names_new):
+        ref = ref.replace(old, new)
+    return ref
+
+
+def test_jaccard_lines():
+    g = G.load_json("f3_jaccard")
+    sets = {n: G.load_case(n)[1] for n in ("g4_part0", "g4_part1", "g4_part2")}
+    for key, pairs, p in (("jaccard_default", [(0, 1), (0, 2)], None), ("jaccard_all", [(0, 1), (0, 2), (1, 2)], None),
+                          ("jaccard_p0.5", [(0, 1)], 0.5)):
+        names = g[key]["inputs"]
+        want = _rename(g[key]["stdout"], names)
+        got = ""
+        for i, j in pairs:
+            a, b, c = zo.split(sets[names[i]], sets[names[j]])
+            got += zo.jaccard_line(names[i], names[j], a + b, a + c, a, p) + "\n"
+        assert got == want
+    # FASTA mode: K = 25, both-strand k-mer set of every record (jaccard.py:100-125)
+    fa = g["jaccard_fasta_all"]
+    recs = [(l[1:].split()[0]) for l in fa["fasta"].split("\n") if l.startswith(">")]
+    seqs = G.fasta_seqs(fa["fasta"])
+    ks = [np.unique(zo.kmers_list(25, s, True)) for s in seqs]
+    got = "%d\n" % len(seqs)
+    for i in range(len(seqs)):
+        for j in range(i + 1, len(seqs)):
+            a, b, c = zo.split(ks[i], ks[j])
+            got += zo.jaccard_line(recs[i], recs[j], len(ks[i]), len(ks[j]), a) + "\n"
+    assert got == fa["stdout"]
+
+
+def test_project_and_sample():
+    _, k0, c0, _, _ = G.load_case("g4_part0")
+    _, k1, _, _, _ = G.load_case("g4_part1")
+    info, pk, pc, _, _ = G.load_case("f3_project_part0_on_part1")
+    ok, oc = zo.project(k1, k0, c0)
+    assert np.array_equal(ok, pk) and np.array_equal(oc, pc)
+    for name in ("f3_sample_D_S5_P0.3", "f3_sample_defaults"):
+        info, sk, sc, _, _ = G.load_case(name)
+        ok, oc = zo.sample_d(info["P"], info["S"], k0, c0)
+        assert np.array_equal(ok, sk) and np.array_equal(oc, sc)
+        assert G.hist_dict(oc) == info["meta"]["hist"]

@@ -228,6 +228,20 @@ int zk_project_dedupe(zk_ctx* c, const uint64_t* d_kmers, uint64_t n, int shift,
     return project_dedupe(c, (const u64*)d_kmers, n, shift, (u64*)d_out, cap, n_out);
 }
 
+int zk_project(zk_ctx* c, const uint64_t* d_ref, uint64_t n_ref, const uint64_t* d_kmers, const uint64_t* d_counts, uint64_t n,
+               uint64_t* d_ok, uint64_t* d_oc, uint64_t cap, uint64_t* n_out) {
+    ZK_ARGS(c, n_out);
+    arena_reset(c);
+    return project(c, (const u64*)d_ref, n_ref, (const u64*)d_kmers, (const u64*)d_counts, n, (u64*)d_ok, (u64*)d_oc, cap, n_out);
+}
+
+int zk_sample(zk_ctx* c, const uint64_t* d_kmers, const uint64_t* d_counts, uint64_t n, uint64_t seed, double p,
+              uint64_t* d_ok, uint64_t* d_oc, uint64_t cap, uint64_t* n_out) {
+    ZK_ARGS(c, n_out);
+    arena_reset(c);
+    return sample_pairs(c, (const u64*)d_kmers, (const u64*)d_counts, n, seed, p, (u64*)d_ok, (u64*)d_oc, cap, n_out);
+}
+
 int zk_split(zk_ctx* c, const uint64_t* d_x, uint64_t nx, const uint64_t* d_y, uint64_t ny, uint64_t abc[3]) {
     ZK_ARGS(c, abc);
     arena_reset(c);

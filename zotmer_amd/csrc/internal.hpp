@@ -96,6 +96,8 @@ int trim(zk_ctx* c, const u64* keys, const void* cnts, int cbits, uint64_t n, u6
          uint64_t cap, uint64_t* n_out);
 int project_dedupe(zk_ctx* c, const u64* keys, uint64_t n, int shift, u64* out, uint64_t cap, uint64_t* n_out);
 int subsample(zk_ctx* c, const u64* keys, uint64_t n, u64 seed, double p, u64* out, uint64_t cap, uint64_t* n_out);
+int sample_pairs(zk_ctx* c, const u64* keys, const u64* cnts, uint64_t n, u64 seed, double p, u64* ok, u64* oc, uint64_t cap,
+                 uint64_t* n_out);
 int subsample_pairs(zk_ctx* c, u64* keys, u32* cnts, uint64_t n, u64 seed, double p, uint64_t* n_out);   // in place
 int encode_list(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int both, u64* out, uint64_t cap, uint64_t* n_out,
                 uint64_t acgt[4]);
@@ -115,5 +117,6 @@ int codec_encode(zk_ctx* c, const u64* d_vals, uint64_t n, int delta, u64* d_wor
 int union_sum(zk_ctx* c, const u64* A, const void* cA, u64 nA, const u64* B, const void* cB, u64 nB, u64* ok, void* oc,
               int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);
 int column_sum(zk_ctx* c, const u64* rows, uint64_t n_rows, int cols, u64* out);   // out[c] = sum of rows[r][c]
+int project(zk_ctx* c, const u64* ref, u64 n_ref, const u64* B, const u64* cB, u64 nB, u64* ok, u64* oc, uint64_t cap, uint64_t* n_out);
 int intersect_count(zk_ctx* c, const u64* A, u64 nA, const u64* B, u64 nB, uint64_t abc[3]);
 }  // namespace zk

@@ -513,6 +513,18 @@ struct SubPairOp {       // K2 applied to an already counted set, in place (load
     __device__ void store(u64 pos, const R& r) const { keys[pos] = r.k; cnts[pos] = r.c; }
 };
 
+struct SampleOp {        // sample.sampleD (zotmer/commands/sample.py:27-34): 40 hash bits as a fraction, in doubles
+    const u64* keys; const u64* cnts; u64 seed; double p; u64* ok; u64* oc;
+    struct R { u64 k; u64 c; };
+    __device__ bool load(u64 idx, R& r) const {
+        r.k = keys[idx]; r.c = cnts[idx];
+        const u64 M = 0xFFFFFFFFFFull;
+        const double u = (double)(murmer(r.k, seed) & M) / (double)M;
+        return u < p;
+    }
+    __device__ void store(u64 pos, const R& r) const { ok[pos] = r.k; oc[pos] = r.c; }
+};
+
 template <class Op>
 __global__ __launch_bounds__(SEL_BLOCK) void select_kernel(Op op, u64 n, u64 cap, SelState st) {
     __shared__ SelSmem sm;
@@ -572,6 +584,11 @@ int project_dedupe(zk_ctx* c, const u64* keys, uint64_t n, int shift, u64* out, 
 int subsample_pairs(zk_ctx* c, u64* keys, u32* cnts, uint64_t n, u64 seed, double p, uint64_t* n_out) {
     SubPairOp op{keys, cnts, seed, p};
     return run_select(c, op, n, n, n_out);
+}
+int sample_pairs(zk_ctx* c, const u64* keys, const u64* cnts, uint64_t n, u64 seed, double p, u64* ok, u64* oc, uint64_t cap,
+                 uint64_t* n_out) {
+    SampleOp op{keys, cnts, seed, p, ok, oc};
+    return run_select(c, op, n, cap, n_out);
 }
 int subsample(zk_ctx* c, const u64* keys, uint64_t n, u64 seed, double p, u64* out, uint64_t cap, uint64_t* n_out) {
     SubsampleOp op{keys, seed, p, out};

@@ -62,7 +62,9 @@ struct MergeState {
     u64* status; u32* ticket; u32 ticket_base; u32 epoch; u32* err; u64* d_total; u32 tiles;
 };
 
-template <typename CT>
+// MODE 0: union with summed counts.  MODE 1: projection (project.project2, zotmer/commands/project.py:29-40):
+// only the B entries whose key also occurs in A survive, with B's own count; A contributes no entry.
+template <typename CT, int MODE>
 __global__ __launch_bounds__(MRG_BLOCK) void union_sum_kernel(const u64* __restrict__ A, const CT* __restrict__ cA, u64 nA,
                                                               const u64* __restrict__ B, const CT* __restrict__ cB, u64 nB,
                                                               const u64* __restrict__ part, u64* __restrict__ ok,
@@ -114,19 +116,21 @@ __global__ __launch_bounds__(MRG_BLOCK) void union_sum_kernel(const u64* __restr
                 // the equal partner, if any, is the B cursor (possibly the right halo)
                 const bool bvalid = (j < nBt) || have_right;
                 CT c = sm.in.ca[1 + i];
-                if (bvalid && bk == ak) {
-                    const CT c2 = c + sm.in.cb[j];
-                    if (c2 < c) atomicOr(st.err, ZK_DERR_COUNT_OVERFLOW);
-                    c = c2;
+                if (MODE == 0) {
+                    if (bvalid && bk == ak) {
+                        const CT c2 = c + sm.in.cb[j];
+                        if (c2 < c) atomicOr(st.err, ZK_DERR_COUNT_OVERFLOW);
+                        c = c2;
+                    }
+                    rk[s] = ak; rc[s] = c; keep |= 1u << s;
                 }
-                rk[s] = ak; rc[s] = c; keep |= 1u << s;
                 i++;
             } else {
                 // dropped when the A element just before it (possibly the left halo) is equal
                 const bool avalid = (i > 0) || have_left;
                 const bool dup = avalid && sm.in.ka[i] == bk;
                 rk[s] = bk; rc[s] = sm.in.cb[j];
-                if (!dup) keep |= 1u << s;
+                if (MODE == 0 ? !dup : dup) keep |= 1u << s;
                 j++;
             }
         }
@@ -247,7 +251,7 @@ static int make_partition(zk_ctx* c, const u64* A, u64 nA, const u64* B, u64 nB,
     return ZK_OK;
 }
 
-template <typename CT>
+template <typename CT, int MODE>
 static int union_sum_t(zk_ctx* c, const u64* A, const CT* cA, u64 nA, const u64* B, const CT* cB, u64 nB, u64* ok, CT* oc,
                        uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]) {
     *n_out = 0;
@@ -262,7 +266,7 @@ static int union_sum_t(zk_ctx* c, const u64* A, const CT* cA, u64 nA, const u64*
     u64* d_rows = nullptr;
     if (acgt_w) ZK_TRY(arena_alloc(c, 32ull * tiles, (void**)&d_rows));
     prof_begin(c, ZK_PROF_UNION, (8 + sizeof(CT)) * (nA + nB));
-    hipLaunchKernelGGL((union_sum_kernel<CT>), dim3(tiles), dim3(MRG_BLOCK), 0, c->stream, A, cA, nA, B, cB, nB, part, ok, oc,
+    hipLaunchKernelGGL((union_sum_kernel<CT, MODE>), dim3(tiles), dim3(MRG_BLOCK), 0, c->stream, A, cA, nA, B, cB, nB, part, ok, oc,
                        (u64)cap, d_rows, st);
     prof_end(c);
     ZK_HIP(c, hipGetLastError());
@@ -279,8 +283,13 @@ static int union_sum_t(zk_ctx* c, const u64* A, const CT* cA, u64 nA, const u64*
 int union_sum(zk_ctx* c, const u64* A, const void* cA, u64 nA, const u64* B, const void* cB, u64 nB, u64* ok, void* oc,
               int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]) {
     if (count_bits == 32)
-        return union_sum_t<u32>(c, A, (const u32*)cA, nA, B, (const u32*)cB, nB, ok, (u32*)oc, cap, n_out, acgt_w);
-    return union_sum_t<u64>(c, A, (const u64*)cA, nA, B, (const u64*)cB, nB, ok, (u64*)oc, cap, n_out, acgt_w);
+        return union_sum_t<u32, 0>(c, A, (const u32*)cA, nA, B, (const u32*)cB, nB, ok, (u32*)oc, cap, n_out, acgt_w);
+    return union_sum_t<u64, 0>(c, A, (const u64*)cA, nA, B, (const u64*)cB, nB, ok, (u64*)oc, cap, n_out, acgt_w);
+}
+
+// the reference's counts are not read in MODE 1, so the keys stand in for A's (absent) count array
+int project(zk_ctx* c, const u64* ref, u64 n_ref, const u64* B, const u64* cB, u64 nB, u64* ok, u64* oc, uint64_t cap, uint64_t* n_out) {
+    return union_sum_t<u64, 1>(c, ref, ref, n_ref, B, cB, nB, ok, oc, cap, n_out, nullptr);
 }
 
 int intersect_count(zk_ctx* c, const u64* A, u64 nA, const u64* B, u64 nB, uint64_t abc[3]) {

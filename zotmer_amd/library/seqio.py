@@ -102,6 +102,24 @@ def fasta_sequences(path):
     return seqs
 
 
+def fasta_records(path):
+    """(name, sequence) per FASTA record, as file.readFasta yields them (library/file.py:19-36): lines are
+    stripped and joined, the name is the header without '>' and surrounding blanks, text before the
+    first header is dropped.  For the small per-record inputs of `zot jaccard`."""
+    name, parts = None, []
+    with open_binary(path) as f:
+        for line in f:
+            line = line.strip()
+            if line[:1] == b">":
+                if name is not None:
+                    yield name, b"".join(parts)
+                name, parts = line[1:].strip().decode("latin-1"), []
+            else:
+                parts.append(line)
+    if name is not None:
+        yield name, b"".join(parts)
+
+
 def fastq_text_batches(path, batch_bytes=1 << 30):
     """Raw FASTQ text in batches that end at line ends, for the device-side parser (zk_fastq_mask):
     yields (bytes, line phase at the start of the batch, records completed inside the batch).  A trailing

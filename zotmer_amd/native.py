@@ -71,6 +71,8 @@ SIGNATURES = {
     "zk_union_sum": (_i, [_vp, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _i, _u64, _pu64, _pu64]),
     "zk_merge_n": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_vp), _pu64, _vp, _vp, _i, _u64, _pu64, _pu64]),
     "zk_project_dedupe": (_i, [_vp, _vp, _u64, _i, _vp, _u64, _pu64]),
+    "zk_project": (_i, [_vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _u64, _pu64]),
+    "zk_sample": (_i, [_vp, _vp, _vp, _u64, _u64, _d, _vp, _vp, _u64, _pu64]),
     "zk_split": (_i, [_vp, _vp, _u64, _vp, _u64, _pu64]),
     "zk_lower_bound": (_i, [_vp, _vp, _u64, _pu64, _u32, _pu64]),
     "zk_trim": (_i, [_vp, _vp, _vp, _i, _u64, _u64, _u64, _vp, _vp, _u64, _pu64]),
@@ -377,6 +379,18 @@ class Context:
         self._check(self.lib.zk_lower_bound(self.h, sorted_keys.ptr, sorted_keys.n, q.ctypes.data_as(_pu64), len(q),
                                             pos.ctypes.data_as(_pu64)))
         return [int(p) for p in pos]
+
+    def project(self, ref, kmers, counts):
+        ok, oc = self.empty(kmers.n, np.uint64), self.empty(kmers.n, np.uint64)
+        n = C.c_uint64(0)
+        self._check(self.lib.zk_project(self.h, ref.ptr, ref.n, kmers.ptr, counts.ptr, kmers.n, ok.ptr, oc.ptr, kmers.n, C.byref(n)))
+        return ok.view(n.value), oc.view(n.value)
+
+    def sample(self, kmers, counts, seed, p):
+        ok, oc = self.empty(kmers.n, np.uint64), self.empty(kmers.n, np.uint64)
+        n = C.c_uint64(0)
+        self._check(self.lib.zk_sample(self.h, kmers.ptr, counts.ptr, kmers.n, int(seed), float(p), ok.ptr, oc.ptr, kmers.n, C.byref(n)))
+        return ok.view(n.value), oc.view(n.value)
 
     def trim(self, kmers, counts, lo, hi=0):
         bits = counts.dtype.itemsize * 8
