@@ -14,6 +14,7 @@ from tests import _golden as G
 from zotmer_amd import native, synth
 
 pytestmark = pytest.mark.gpu
+DEFAULT_SORT_VARIANT = 3       # zk_ctx defaults (internal.hpp)
 
 
 @pytest.fixture(scope="module")
@@ -87,6 +88,25 @@ def test_sort_keys(ctx, n, bits):
         x &= np.uint64((1 << bits) - 1)
     got = ctx.sort_keys(ctx.upload(x), bits).to_host()
     assert np.array_equal(got, np.sort(x))
+
+
+@pytest.mark.parametrize("variant", range(5))
+def test_sort_keys_every_geometry(ctx, variant):
+    """every instantiated tile geometry / look-back scheme (zk_tune): same result, stable for pairs"""
+    try:
+        ctx.tune(sort_variant=variant, pairs_variant=variant)
+        for n in (1, 8192, 8192 * 33 + 7, 8192 * 200 + 4097):          # 1 tile; > one segment; several segments
+            rng = np.random.default_rng(n + variant)
+            x = rng.integers(0, 1 << 50, size=n, dtype=np.uint64)
+            x[n // 3: n // 3 + min(n // 4, 40000)] = x[0]                # a skewed digit on top
+            assert np.array_equal(ctx.sort_keys(ctx.upload(x), 50).to_host(), np.sort(x))
+            k = (x >> np.uint64(38)) << np.uint64(20)
+            v = np.arange(n, dtype=np.uint32)
+            dk, dv = ctx.sort_pairs(ctx.upload(k), ctx.upload(v), 50)
+            order = np.argsort(k, kind="stable")
+            assert np.array_equal(dk.to_host(), k[order]) and np.array_equal(dv.to_host(), v[order])
+    finally:
+        ctx.tune(sort_variant=DEFAULT_SORT_VARIANT, pairs_variant=DEFAULT_SORT_VARIANT)
 
 
 def test_sort_keys_adversarial(ctx):

@@ -23,7 +23,8 @@ def main():
     for v in variants:
         ctx.tune(sort_variant=v)
         res = {}
-        for rep in range(2):
+        best = None
+        for rep in range(4):
             ctx._check(ctx.lib.zk_copy(ctx.h, work.ptr, src.ptr, 8 * n))
             ctx.sync()
             ctx.profile(True)
@@ -32,6 +33,12 @@ def main():
             dt = time.perf_counter() - t0
             res = ctx.profile_read()
             ctx.profile(False)
+            pm = res["pass_keys"]["ms"] / res["pass_keys"]["launches"]
+            if best is None or pm < best[0]:
+                best = (pm, res, dt)
+        pm, res, dt = best
+        if True:
+            pass
         pk = res["pass_keys"]
         h = work.to_host(1 << 20)
         ok = bool(np.all(h[1:] >= h[:-1]))

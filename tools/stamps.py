@@ -9,7 +9,7 @@ from zotmer_amd import native
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1 << 28
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-tile = {0: 8192, 3: 8192, 1: 4096, 2: 16384}[variant]
+tile = {0: 8192, 3: 8192, 1: 4096, 2: 8192, 4: 8192, 5: 8192, 6: 8192, 7: 8192}[variant]
 ctx = native.Context(0)
 ctx.tune(sort_variant=variant)
 rng = np.random.default_rng(1)
@@ -27,9 +27,21 @@ ss = raw[tiles * 8:]
 steps = (ss >> np.uint64(32)).astype(np.int64)[1:]
 spins = (ss & np.uint64(0xFFFFFFFF)).astype(np.int64)[1:]
 d = np.diff(s, axis=1)
+pipe = variant == 3
+if pipe:
+    ok = (s[:, 7] > 0) & (s[:, 0] > 0)
+    s = s[ok]
+    seq = [("load wait", 0, 1), ("rank (wave 0)", 1, 2), ("barrier + scan + publish", 2, 4), ("parked (other tile's work)", 4, 3),
+           ("look-back (thread 0)", 3, 5), ("barrier after look-back", 5, 6), ("store", 6, 7)]
+    tot = s[:, 7] - s[:, 0]
+    print(json.dumps({"hops_mean": float(steps.mean()), "polls_mean": float(spins.mean()), "polls_p50_p90_p99": [float(np.percentile(spins, q)) for q in (50, 90, 99)],
+                      "tiles": int(len(s)), "median_ticks_ticket_to_stored": float(np.median(tot)),
+                      "phases_median_ticks": {nm: float(np.median(s[:, b] - s[:, a])) for nm, a, b in seq}}, indent=1))
+    sys.exit(0)
 names = ["load wait", "rank (wave 0)", "barrier after rank", "digit scan", "look-back (thread 0)", "barrier after look-back", "regroup + store"]
 tot = (s[:, 7] - s[:, 0])
-print(json.dumps({"steps_hist": np.bincount(np.minimum(steps, 12)).tolist(), "spins_mean": float(spins.mean()), "spins_p50_p90_p99": [float(np.percentile(spins, q)) for q in (50, 90, 99)],
+print(json.dumps({"steps_mean": float(steps.mean()), "steps_p10_p50_p90_p99": [float(np.percentile(steps, q)) for q in (10, 50, 90, 99)],
+                  "ticks_per_step_median": float(np.median(d[1:, 4] / np.maximum(steps, 1))), "spins_mean": float(spins.mean()), "spins_p50_p90_p99": [float(np.percentile(spins, q)) for q in (50, 90, 99)],
                   "frac_tiles_with_spin": float((spins > 0).mean()),
                   "tiles": int(tiles), "median_total_ticks": float(np.median(tot)),
                   "phases_median_ticks": {nm: float(np.median(d[:, i])) for i, nm in enumerate(names)},

@@ -95,7 +95,7 @@ __device__ __forceinline__ u64 st_state(u64 w, u32 epoch) {
 __device__ __forceinline__ u32 take_ticket(u32* counter, u32* lds_slot) {
     if (threadIdx.x == 0) *lds_slot = atomicAdd(counter, 1u);
     __syncthreads();
-    return *lds_slot;
+    return (u32)__builtin_amdgcn_readfirstlane((int)*lds_slot);   // the same in every lane: keep it in an SGPR
 }
 
 // One value per tile.  Called by all 64 lanes of ONE wave of the workgroup; returns the sum of

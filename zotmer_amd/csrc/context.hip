@@ -105,6 +105,19 @@ int lookback_begin(zk_ctx* c, uint64_t words, uint32_t tiles, u32* epoch, u32* t
     return ZK_OK;
 }
 
+int part16_begin(zk_ctx* c, uint64_t words, unsigned short** out) {
+    if (words > c->part16_words) {
+        ZK_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->part16) { ZK_HIP(c, hipFree(c->part16)); c->part16 = nullptr; c->part16_words = 0; }
+        const uint64_t w = words + words / 8 + 4096;
+        ZK_HIP(c, hipMalloc((void**)&c->part16, w * sizeof(unsigned short)));
+        c->part16_words = w;
+    }
+    ZK_HIP(c, hipMemsetAsync(c->part16, 0, words * sizeof(unsigned short), c->stream));
+    *out = c->part16;
+    return ZK_OK;
+}
+
 int check_device_error(zk_ctx* c) {
     u32 e = 0;
     ZK_HIP(c, hipMemcpyAsync(&e, c->d_err, sizeof(u32), hipMemcpyDeviceToHost, c->stream));
@@ -184,6 +197,7 @@ void zk_destroy(zk_ctx* c) {
     if (c->arena) (void)hipFree(c->arena);
     if (c->aux) (void)hipFree(c->aux);
     if (c->status) (void)hipFree(c->status);
+    if (c->part16) (void)hipFree(c->part16);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_scalars) (void)hipFree(c->d_scalars);

@@ -33,6 +33,8 @@ struct zk_ctx {
     // decoupled look-back state (persistent: cleared once per 31 launches, see common.hpp)
     u64* status = nullptr;
     uint64_t status_words = 0;
+    unsigned short* part16 = nullptr;   // radix sort: per-tile digit counts, 16 bits each (radix_sort.hip)
+    uint64_t part16_words = 0;
     u32 epoch = 0;
     u32* d_ticket = nullptr;   // monotonically increasing tile ticket
     u32 ticket_base = 0;
@@ -72,6 +74,8 @@ int arena_require(zk_ctx* c, uint64_t want, uint64_t must);
 int aux_require(zk_ctx* c, uint64_t bytes, char** p);   // grows (free + malloc) when too small
 // look-back state for one launch that needs `words` status words and `tiles` tickets
 int lookback_begin(zk_ctx* c, uint64_t words, uint32_t tiles, u32* epoch, u32* ticket_base);
+// zeroed 16-bit words for one sort pass (grow-only buffer, cleared on the stream)
+int part16_begin(zk_ctx* c, uint64_t words, unsigned short** out);
 // read and clear the device error word (after a stream sync); maps it to a ZK_E* code
 int check_device_error(zk_ctx* c);
 

@@ -32,10 +32,18 @@ constexpr int MAX_RADIX = 1024;
 
 enum { SRC_ARRAY = 0, SRC_STREAM = 1 };
 
-template <int BLOCK_, int ITEMS_, int RBITS_>
+// ROUNDS: the LDS regroup buffer holds TILE/ROUNDS keys and the tile leaves in that many rounds (less
+// LDS per workgroup -> more workgroups per CU).  WPE: waves per SIMD the register allocator must allow.
+// SEG: tiles per look-back segment (power of two; 0 = one serial chain per digit over all tiles).
+// PIPE: array passes of keys run as the persistent two-stage pipeline (pass_pipe_kernel).
+template <int BLOCK_, int ITEMS_, int RBITS_, int ROUNDS_ = 1, int WPE_ = 1, int SEG_ = 32, bool PIPE_ = false>
 struct Cfg {
-    static constexpr int BLOCK = BLOCK_, ITEMS = ITEMS_, RBITS = RBITS_;
+    static constexpr int BLOCK = BLOCK_, ITEMS = ITEMS_, RBITS = RBITS_, ROUNDS = ROUNDS_, WPE = WPE_, SEG = SEG_;
+    static constexpr bool PIPE = PIPE_;
+    static_assert(SEG == 0 || (BLOCK * ITEMS < 32768 && (SEG & (SEG - 1)) == 0), "16-bit tile counts");
     static constexpr int TILE = BLOCK * ITEMS, RADIX = 1 << RBITS, NW = BLOCK / 64;
+    static constexpr int EXCH = TILE / ROUNDS, IPR = ITEMS / ROUNDS;   // slots / items per thread per round
+    static_assert(ITEMS % ROUNDS == 0, "ROUNDS");
     static constexpr int DPT = (RADIX + BLOCK - 1) / BLOCK;   // digits per thread in the per-digit steps
     static_assert(ITEMS % 2 == 0 && 2 * ITEMS < 256, "ITEMS");
     static_assert(64 * ITEMS < 65536, "per-wave ranks are 16-bit");
@@ -81,6 +89,7 @@ struct SortArgs {
     int bits;
     const u64* ghist;   // [RADIX] exclusive prefix of this pass's digit over all keys
     // look-back
+    u16* part;          // [tiles][RADIX] 0x8000 | count of the digit in the tile (segmented scheme)
     u64* status;
     u32* ticket;
     u32 ticket_base;
@@ -106,7 +115,7 @@ template <class C, int SRC, bool PAIRS, bool COUNT>
 __device__ __forceinline__ u32 load_tile(const SortArgs& a, u32 tile, TileImage<C::TILE>* img, u64 (&key)[C::ITEMS],
                                          u32 (&val)[C::ITEMS], u32& acgt) {
     constexpr int TILE = C::TILE, ITEMS = C::ITEMS, BLOCK = C::BLOCK;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     u32 live = 0;
     if (SRC == SRC_ARRAY) {
         const u64 base = (u64)tile * TILE + (u64)wave * (64 * ITEMS) + lane;
@@ -253,7 +262,7 @@ __global__ void hist_scan_kernel(u64* ghist, int passes, int radix, u64* n_out) 
 template <class C>
 struct PassSmem {
     union {
-        u64 exch[C::TILE];
+        u64 exch[C::EXCH];
         TileImage<C::TILE> img;
     };
     u16 cnt[C::NW][C::RADIX];
@@ -266,8 +275,9 @@ struct PassSmem {
 
 // Walk back over the predecessors of `tile` for one digit: add PARTIAL counts until an INCLUSIVE
 // prefix is met.  `q` points at the word of tile-1.  A word that is not published yet is polled again.
-__device__ __forceinline__ u64 lookback_walk(const u64* q, u32 tile, int radix, u32 epoch, u32* err) {
+__device__ __forceinline__ u64 lookback_walk(const u64* q, u32 tile, int radix, u32 epoch, u32* err, u64* stat = nullptr) {
     u64 excl = 0;
+    u32 steps = 0, polls = 0;
     for (u32 t = tile; t > 0; t--, q -= radix) {
         u64 w = ld_agent(q);
         int spins = 0;
@@ -276,17 +286,81 @@ __device__ __forceinline__ u64 lookback_walk(const u64* q, u32 tile, int radix, 
             __builtin_amdgcn_s_sleep(1);
             w = ld_agent(q);
         }
+        steps++; polls += (u32)spins;
         excl += w & ZK_ST_VALUE_MASK;
         if (st_state(w, epoch) != ZK_ST_PARTIAL) break;   // INCLUSIVE (or gave up)
     }
+    if (stat) *stat = ((u64)steps << 32) | polls;
     return excl;
 }
 
+// ---------------------------------------------------------------------------------------
+// Segmented look-back.  Status reads are what the serial chain spends its time and its memory
+// requests on (17 dependent 8-byte polls per digit per tile, measured), so:
+//   * a tile publishes its digit counts as 16-bit words (bit 15 = valid; the array is cleared per pass);
+//   * tiles are grouped in segments of SEG; a tile adds up the counts of the tiles before it in ITS
+//     segment -- a known set, so the loads are independent and issued together;
+//   * the last tile of segment g publishes the segment's counts as 64-bit epoch-tagged words (PARTIAL),
+//     and the prefix through the segment (INCLUSIVE) once it knows it; every tile runs the usual
+//     decoupled look-back over those SEGMENT words -- SEG times fewer of them arrive per microsecond than
+//     tile words, so the walk is one to three hops.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ u16 ld_agent16(const u16* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent16(u16* p, u16 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int SEG, int RADIX, bool PUBLISH = true>
+__device__ __forceinline__ u64 lookback_segmented(const SortArgs& a, u32 tile, int d, u32 count, u64* stat) {
+    const u32 seg = tile / SEG, pos = tile % SEG;
+    u16* row = a.part + (u64)tile * RADIX + d;
+    if (PUBLISH) st_agent16(row, (u16)(0x8000u | count));
+    u64* sw = a.status + (u64)seg * RADIX + d;          // this segment's word; earlier segments lie below it
+    u64 bw = (seg > 0) ? ld_agent(sw - RADIX) : st_pack(ZK_ST_INCLUSIVE, a.epoch, 0);   // first hop, issued early
+    u32 sum = 0, polls = 0;
+    for (u32 i0 = 1; i0 <= pos; i0 += 8) {       // pos is uniform over the workgroup
+        u16 w[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = (i0 + k <= pos) ? ld_agent16(row - (long long)(i0 + k) * RADIX) : (u16)0x8000u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            u16 x = w[k];
+            int spins = 0;
+            while (!(x & 0x8000u)) {
+                if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT); break; }
+                __builtin_amdgcn_s_sleep(1);
+                x = ld_agent16(row - (long long)(i0 + k) * RADIX);
+            }
+            polls += (u32)spins;
+            sum += x & 0x7fffu;
+        }
+    }
+    const bool last = (pos == SEG - 1);
+    if (last && seg > 0) st_agent(sw, st_pack(ZK_ST_PARTIAL, a.epoch, sum + count));
+    // decoupled look-back over the segment words: PARTIAL = that segment's total, INCLUSIVE = prefix through it
+    u64 base = 0;
+    u32 hops = 0;
+    const u64* q = sw - RADIX;
+    for (u32 g = seg; g > 0; g--, q -= RADIX) {
+        u64 w = (g == seg) ? bw : ld_agent(q);
+        int spins = 0;
+        while (st_state(w, a.epoch) == 0) {
+            if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT); break; }
+            __builtin_amdgcn_s_sleep(1);
+            w = ld_agent(q);
+        }
+        polls += (u32)spins; hops++;
+        base += w & ZK_ST_VALUE_MASK;
+        if (st_state(w, a.epoch) != ZK_ST_PARTIAL) break;
+    }
+    if (last) st_agent(sw, st_pack(ZK_ST_INCLUSIVE, a.epoch, base + sum + count));
+    if (stat) *stat = ((u64)hops << 32) | polls;
+    return base + sum;
+}
+
 template <class C, int SRC, bool PAIRS>
-__global__ __launch_bounds__(C::BLOCK) void pass_kernel(SortArgs a) {
+__global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_kernel(SortArgs a) {
     constexpr int BLOCK = C::BLOCK, ITEMS = C::ITEMS, RADIX = C::RADIX, NW = C::NW, DPT = C::DPT;
     __shared__ PassSmem<C> sm;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     const u32 tile = take_ticket(a.ticket, &sm.ticket) - a.ticket_base;
     ZK_STAMP(0);
@@ -369,23 +443,23 @@ __global__ __launch_bounds__(C::BLOCK) void pass_kernel(SortArgs a) {
     for (int j = 0; j < DPT; j++) {
         const int d = tid * DPT + j;
         if (d < RADIX) {
-            u64* st = a.status + (u64)tile * RADIX + d;
             u64 excl = 0;
-            if (tile == 0) {
-                st_agent(st, st_pack(ZK_ST_INCLUSIVE, a.epoch, tcount[j]));
-            } else {
-                st_agent(st, st_pack(ZK_ST_PARTIAL, a.epoch, tcount[j]));
-#ifdef ZK_NO_LOOKBACK   /* timing experiment only: results are wrong */
-                {   // stay inside the digit's bin so every store is in range
-                    const u64 lo = a.ghist[d], hi = (d + 1 < RADIX) ? a.ghist[d + 1] : a.n;
-                    const u64 room = (hi - lo >= tcount[j]) ? (hi - lo - tcount[j]) : 0;
-                    excl = (u64)tile * tcount[j];
-                    if (excl > room) excl = room;
-                }
+#ifdef ZK_STAMPS
+            u64* stat = (a.dbg2 && tid == 0) ? a.dbg2 + tile : nullptr;
 #else
-                excl = lookback_walk(st - RADIX, tile, RADIX, a.epoch, a.err);
+            u64* stat = nullptr;
 #endif
-                st_agent(st, st_pack(ZK_ST_INCLUSIVE, a.epoch, excl + tcount[j]));
+            if (C::SEG > 0) {
+                excl = lookback_segmented<(C::SEG > 0 ? C::SEG : 1), RADIX>(a, tile, d, tcount[j], stat);
+            } else {
+                u64* st = a.status + (u64)tile * RADIX + d;
+                if (tile == 0) {
+                    st_agent(st, st_pack(ZK_ST_INCLUSIVE, a.epoch, tcount[j]));
+                } else {
+                    st_agent(st, st_pack(ZK_ST_PARTIAL, a.epoch, tcount[j]));
+                    excl = lookback_walk(st - RADIX, tile, RADIX, a.epoch, a.err, stat);
+                    st_agent(st, st_pack(ZK_ST_INCLUSIVE, a.epoch, excl + tcount[j]));
+                }
             }
             sm.digit_off[d] = dig_excl;
             sm.gbase[d] = a.ghist[d] + excl - dig_excl;
@@ -396,43 +470,317 @@ __global__ __launch_bounds__(C::BLOCK) void pass_kernel(SortArgs a) {
     __syncthreads();
     ZK_STAMP(6);         // every chain done
 
-    // ---- regroup the tile by digit in LDS ---------------------------------------------------
+    // ---- regroup the tile by digit in LDS, EXCH slots at a time ------------------------------
+    constexpr int EXCH = C::EXCH, IPR = C::IPR;
     u32 lpos[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const u32 d = (u32)(key[i] >> a.shift) & dmask;
-        lpos[i] = sm.digit_off[d] + sm.cnt[wave][d] + rank[i];
-        if ((live >> i) & 1u) sm.exch[lpos[i]] = key[i];
+        lpos[i] = ((live >> i) & 1u) ? sm.digit_off[d] + sm.cnt[wave][d] + rank[i] : ~0u;
     }
-    __syncthreads();
-    const u32 total = sm.total_live;
-    u64 gpos[ITEMS];
+    const u32 total = sm.total_live;   // written before the barrier that ended the look-back
+    u32* exv = reinterpret_cast<u32*>(sm.exch);
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        const u32 s = tid + i * BLOCK;
-        gpos[i] = ~0ull;
-        if (s < total) {
-            const u64 k = sm.exch[s];
-            const u32 d = (u32)(k >> a.shift) & dmask;
-            gpos[i] = sm.gbase[d] + s;
-            a.kout[gpos[i]] = k;
+    for (int r = 0; r < C::ROUNDS; r++) {
+        const u32 lo = (u32)r * EXCH;
+        if (r > 0) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++)
+            if (lpos[i] - lo < (u32)EXCH) sm.exch[lpos[i] - lo] = key[i];
+        __syncthreads();
+        u64 gpos[IPR];
+#pragma unroll
+        for (int i = 0; i < IPR; i++) {
+            const u32 s = tid + i * BLOCK;
+            gpos[i] = ~0ull;
+            if (lo + s < total) {
+                const u64 k = sm.exch[s];
+                const u32 d = (u32)(k >> a.shift) & dmask;
+                gpos[i] = sm.gbase[d] + lo + s;
+                a.kout[gpos[i]] = k;
+            }
+        }
+        if (PAIRS) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++)
+                if (lpos[i] - lo < (u32)EXCH) exv[lpos[i] - lo] = val[i];
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < IPR; i++) {
+                const u32 s = tid + i * BLOCK;
+                if (lo + s < total) a.vout[gpos[i]] = exv[s];
+            }
         }
     }
 #ifdef ZK_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     ZK_STAMP(7);         // keys stored
 #endif
-    if (PAIRS) {
+}
+
+// ---------------------------------------------------------------------------------------
+// The same pass as a persistent, two-stage pipeline (array source, keys only).
+//
+// Measured on the one-tile-per-workgroup kernel: a tile spends a third of its life in the look-back,
+// and nearly all of that is polling words that its neighbours -- started within a microsecond of it --
+// have stored but that are not visible yet.  Waiting cannot be made shorter, so it is filled: a
+// workgroup ranks tile B and publishes B's counts BEFORE it resolves the offsets of tile A, which it
+// ranked one iteration earlier and parked, already grouped by digit, in LDS.  By then A's neighbours
+// published 10 us ago and the look-back finds everything in place.
+//
+// Progress: a ticket, once taken, is ranked and published without waiting for any other tile, so every
+// count a look-back waits for is on its way.
+// ---------------------------------------------------------------------------------------
+#ifdef ZK_STAMPS
+#define PSTAMP(t, k) do { if (a.dbg && threadIdx.x == 0) a.dbg[(u64)(t) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PSTAT(t) ((a.dbg2 && threadIdx.x == 0) ? a.dbg2 + (t) : nullptr)
+#else
+#define PSTAMP(t, k) do { } while (0)
+#define PSTAT(t) nullptr
+#endif
+template <class C>
+__global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a, u32 tiles) {
+    constexpr int BLOCK = C::BLOCK, ITEMS = C::ITEMS, RADIX = C::RADIX, NW = C::NW, DPT = C::DPT, TILE = C::TILE;
+    static_assert(C::ROUNDS == 1, "the pipeline parks a whole tile in LDS");
+    constexpr int NS = RADIX / 64;          // scanner workgroups: 64 digits each
+    __shared__ PassSmem<C> sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 dmask = (1u << a.bits) - 1u;
+    u16* mycnt = sm.cnt[wave];
+
+    // ---- the first NS tickets are the scanners ------------------------------------------------------
+    // A scanner workgroup owns 64 digits (one per lane).  Its NW waves take the tiles in batches of U, wave w
+    // the batches w, w+NW, ...: read the U 16-bit counts (independent loads), add them up, take the running
+    // total from the wave before through one LDS word per digit (sequence number | total), pass it on, and
+    // only then write the U exclusive offsets (64-bit, epoch-tagged).  The chain between batches is an LDS
+    // round trip; the slow parts -- global loads and store acknowledgements -- overlap across the waves.
+    // Scanners hold the oldest tickets of the launch, hence they are resident, and every count they wait
+    // for is published by a workgroup that holds a ticket.
+    const u32 first = take_ticket(a.ticket, &sm.ticket) - a.ticket_base;
+    if (first < (u32)NS) {
+        constexpr int U = 32;
+        u64* carry = sm.exch;                       // [64]: batch number << 40 | running total
+        if (tid < 64) carry[tid] = 0;
         __syncthreads();
-        u32* exv = reinterpret_cast<u32*>(sm.exch);
+        const int d = (int)first * 64 + lane;
+        const u16* src = a.part + d;
+        u64* dst = a.status + d;
+        const u32 batches = (tiles + U - 1) / U;
+        for (u32 b = (u32)wave; b < batches; b += NW) {
+            const u32 t0 = b * U;
+            u16 x[U];
 #pragma unroll
-        for (int i = 0; i < ITEMS; i++)
-            if ((live >> i) & 1u) exv[lpos[i]] = val[i];
-        __syncthreads();
+            for (int k = 0; k < U; k++) x[k] = (t0 + k < tiles) ? ld_agent16(src + (u64)(t0 + k) * RADIX) : (u16)0x8000u;
+            u32 sum = 0;
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                u16 v = x[k];
+                int spins = 0;
+                while (!(v & 0x8000u)) {
+                    if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                    v = ld_agent16(src + (u64)(t0 + k) * RADIX);
+                }
+                x[k] = v & 0x7fffu;
+                sum += x[k];
+            }
+            // hand-off: wait for batch b-1's total
+            volatile u64* cw = carry + lane;
+            u64 cv = *cw;
+            int spins = 0;
+            while ((u32)(cv >> 40) != b) {
+                if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT); break; }
+                __builtin_amdgcn_s_sleep(1);
+                cv = *cw;
+            }
+            u64 run = cv & ((1ull << 40) - 1);
+            *cw = ((u64)(b + 1) << 40) | (run + sum);
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                if (t0 + k < tiles) st_agent(dst + (u64)(t0 + k) * RADIX, st_pack(ZK_ST_INCLUSIVE, a.epoch, run));
+                run += x[k];
+            }
+        }
+        return;
+    }
+    bool have = false;
+    u32 tileA = 0, totalA = 0;
+    u32 tcA[DPT], dexA[DPT];
+#pragma unroll
+    for (int j = 0; j < DPT; j++) { tcA[j] = 0; dexA[j] = 0; }
+
+    // Software pipeline over the tickets: C's ticket is asked for while B is ranked, an iteration early.
+    u32 tB = first - NS;
+    bool vB = tB < tiles;
+    u64 keyN[ITEMS];
+    u32 liveN = 0, pending = 0;
+    auto issue_loads = [&](u32 t) {
+        const u64 base = (u64)t * TILE + (u64)wave * (64 * ITEMS) + lane;
+        liveN = 0;
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
-            const u32 s = tid + i * BLOCK;
-            if (s < total) a.vout[gpos[i]] = exv[s];
+            const u64 idx = base + (u64)i * 64;
+            const bool ok = idx < a.n;
+            keyN[i] = ok ? a.kin[idx] : 0ull;
+            liveN |= (ok ? 1u : 0u) << i;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) keyN[i] = 0;
+    if (vB) {
+        if (tid == 0) pending = atomicAdd(a.ticket, 1u);     // the ticket of the tile AFTER the one being loaded
+        issue_loads(tB);
+    }
+
+    for (;;) {
+        if (!vB && !have) break;
+        PSTAMP(tB, 0);
+        u64 key[ITEMS];
+        u32 rank2[ITEMS / 2];          // two 16-bit ranks per register
+        u32 live = 0;
+        u32 tC = 0;
+        bool vC = false;
+        u32 tcB[DPT], dexB[DPT];
+        u64 rowA[DPT];
+#pragma unroll
+        for (int j = 0; j < DPT; j++) { tcB[j] = 0; dexB[j] = 0; rowA[j] = 0; }
+
+        if (vB) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) key[i] = keyN[i];
+            live = liveN;
+            for (int d = lane; d < RADIX; d += 64) mycnt[d] = 0;
+            __syncthreads();
+#ifdef ZK_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            PSTAMP(tB, 1);
+            // ---- rank inside the wave (see pass_kernel) ------------------------------------------
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const bool lv = (live >> i) & 1u;
+                const u32 d = (u32)(key[i] >> a.shift) & dmask;
+                const u64 lm = __ballot(lv);
+                u32 plo = (u32)lm, phi = (u32)(lm >> 32);
+#pragma unroll
+                for (int b = 0; b < C::RBITS; b++) {
+                    const u32 B = (u32)__builtin_amdgcn_sbfe((int)d, b, 1);
+                    const u64 m = __ballot(B != 0);
+                    plo &= ~((u32)m ^ B);
+                    phi &= ~((u32)(m >> 32) ^ B);
+                }
+                const u32 below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+                const u32 npeer = (u32)__popc(plo) + (u32)__popc(phi);
+                const u32 pre = lv ? (u32)mycnt[d] : 0u;
+                if (i & 1) rank2[i / 2] |= (pre + below) << 16; else rank2[i / 2] = pre + below;
+                if (lv && below == npeer - 1) mycnt[d] = (u16)(pre + npeer);
+            }
+            PSTAMP(tB, 2);
+            // the atomic was issued before this tile's key loads, so it has returned by now (no extra wait)
+            if (tid == 0) sm.ticket = pending;
+            if (have) {
+#pragma unroll
+                for (int j = 0; j < DPT; j++) {
+                    const int d = tid * DPT + j;
+                    if (d < RADIX) rowA[j] = ld_agent(a.status + (u64)tileA * RADIX + d);   // consumed after B is published
+                }
+            }
+            __syncthreads();
+            tC = (u32)__builtin_amdgcn_readfirstlane((int)sm.ticket) - a.ticket_base - NS;
+            vC = tC < tiles;
+            // ---- per digit: scan over the waves, publish the tile's count at once -------------------
+            u32 tsum = 0;
+#pragma unroll
+            for (int j = 0; j < DPT; j++) {
+                const int d = tid * DPT + j;
+                u32 acc = 0;
+                if (d < RADIX) {
+#pragma unroll
+                    for (int w = 0; w < NW; w++) {
+                        const u32 t = sm.cnt[w][d];
+                        sm.cnt[w][d] = (u16)acc;
+                        acc += t;
+                    }
+                    st_agent16(a.part + (u64)tB * RADIX + d, (u16)(0x8000u | acc));
+                }
+                tcB[j] = acc;
+                tsum += acc;
+            }
+            const u32 inc = wave_incl_scan_u32(tsum);
+            if (lane == 63) sm.wsum[wave] = inc;
+            __syncthreads();
+            u32 woff = 0;
+            for (int w = 0; w < wave; w++) woff += sm.wsum[w];
+            u32 run = woff + inc - tsum;
+            if (tid == BLOCK - 1) sm.total_live = woff + inc;
+#pragma unroll
+            for (int j = 0; j < DPT; j++) {
+                const int d = tid * DPT + j;
+                dexB[j] = run;
+                if (d < RADIX) sm.digit_off[d] = run;
+                run += tcB[j];
+            }
+        }
+
+        if (vB) PSTAMP(tB, 4);
+        if (have) {
+            PSTAMP(tileA, 3);
+            // ---- tile A: offsets, then out of LDS ------------------------------------------------
+#pragma unroll
+            for (int j = 0; j < DPT; j++) {
+                const int d = tid * DPT + j;
+                if (d < RADIX) {
+                    const u64* q = a.status + (u64)tileA * RADIX + d;
+                    u64 w = vB ? rowA[j] : ld_agent(q);
+                    int spins = 0;
+                    while (st_state(w, a.epoch) == 0) {
+                        if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        w = ld_agent(q);
+                    }
+#ifdef ZK_STAMPS
+                    if (PSTAT(tileA)) *PSTAT(tileA) = (1ull << 32) | (u32)spins;
+#endif
+                    sm.gbase[d] = a.ghist[d] + (w & ZK_ST_VALUE_MASK) - dexA[j];
+                }
+            }
+            PSTAMP(tileA, 5);
+            __syncthreads();
+            PSTAMP(tileA, 6);
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const u32 sl = tid + i * BLOCK;
+                if (sl < totalA) {
+                    const u64 k = sm.exch[sl];
+                    const u32 d = (u32)(k >> a.shift) & dmask;
+                    a.kout[sm.gbase[d] + sl] = k;
+                }
+            }
+        }
+#ifdef ZK_STAMPS
+        if (have) { PSTAMP(tileA, 7); }
+#endif
+        if (!vB) break;
+        __syncthreads();      // exch is free again; digit_off / total_live of B are visible
+        // ---- park B, grouped by digit ------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const u32 d = (u32)(key[i] >> a.shift) & dmask;
+            if ((live >> i) & 1u) sm.exch[sm.digit_off[d] + sm.cnt[wave][d] + ((rank2[i / 2] >> (16 * (i & 1))) & 0xffffu)] = key[i];
+        }
+        tileA = tB;
+        totalA = sm.total_live;
+#pragma unroll
+        for (int j = 0; j < DPT; j++) { tcA[j] = tcB[j]; dexA[j] = dexB[j]; }
+        have = true;
+        tB = tC;
+        vB = vC;
+        // Loading C any earlier (while B's keys and ranks are live) costs more in spilled registers than
+        // the hidden latency gives back (measured: 2.87 vs 3.13 TB/s), so the loads start here.
+        if (vB) {
+            if (tid == 0) pending = atomicAdd(a.ticket, 1u);
+            issue_loads(tB);
         }
     }
 }
@@ -452,7 +800,12 @@ struct Sorter {
     static int launch_pass(zk_ctx* c, SortArgs a) {
         const u32 tiles = tiles_for(a, SRC);
         if (tiles == 0) return ZK_OK;
-        ZK_TRY(lookback_begin(c, (uint64_t)tiles * C::RADIX, tiles, &a.epoch, &a.ticket_base));
+        if (C::SEG > 0) {
+            ZK_TRY(lookback_begin(c, ((uint64_t)tiles / C::SEG + 2) * C::RADIX, tiles, &a.epoch, &a.ticket_base));
+            ZK_TRY(part16_begin(c, (uint64_t)tiles * C::RADIX, &a.part));
+        } else {
+            ZK_TRY(lookback_begin(c, (uint64_t)tiles * C::RADIX, tiles, &a.epoch, &a.ticket_base));
+        }
         a.status = c->status;
         a.ticket = c->d_ticket;
         a.err = c->d_err;
@@ -464,6 +817,33 @@ struct Sorter {
         prof_end(c);
         ZK_HIP(c, hipGetLastError());
         return ZK_OK;
+    }
+
+    // persistent pipelined pass (array source, keys only)
+    static int launch_pipe(zk_ctx* c, SortArgs a) {
+      if constexpr (C::PIPE) {
+        const u32 tiles = tiles_for(a, SRC_ARRAY);
+        if (tiles == 0) return ZK_OK;
+        u32 grid = (u32)c->num_cus * 2;
+        if (grid > tiles) grid = tiles;
+        grid += C::RADIX / 64;          // the scanner workgroups
+        ZK_TRY(lookback_begin(c, (uint64_t)tiles * C::RADIX, tiles + grid, &a.epoch, &a.ticket_base));
+        ZK_TRY(part16_begin(c, (uint64_t)tiles * C::RADIX, &a.part));
+        a.status = c->status;
+        a.ticket = c->d_ticket;
+        a.err = c->d_err;
+        a.dbg = c->dbg;
+        a.dbg2 = c->dbg ? c->dbg + 8ull * tiles : nullptr;
+        prof_begin(c, ZK_PROF_PASS_KEYS, 16 * a.n);
+        hipLaunchKernelGGL((pass_pipe_kernel<C>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
+        prof_end(c);
+        ZK_HIP(c, hipGetLastError());
+      }
+      return ZK_OK;
+    }
+    static int launch_keys_pass(zk_ctx* c, const SortArgs& a) {
+        if (C::PIPE) return launch_pipe(c, a);
+        return launch_pass<SRC_ARRAY, false>(c, a);
     }
 
     template <int SRC>
@@ -498,7 +878,7 @@ struct Sorter {
         for (int p = 0; p < plan.passes; p++) {
             a.kin = in; a.kout = out; a.shift = plan.shift[p]; a.bits = plan.bits[p];
             a.ghist = ghist + p * C::RADIX;
-            ZK_TRY((launch_pass<SRC_ARRAY, false>(c, a)));
+            ZK_TRY(launch_keys_pass(c, a));
             u64* t = in; in = out; out = t;
         }
         *result = in;
@@ -551,7 +931,7 @@ struct Sorter {
         for (int p = 1; p < plan.passes; p++) {
             a.kin = in; a.kout = out; a.shift = plan.shift[p]; a.bits = plan.bits[p];
             a.ghist = ghist + p * C::RADIX;
-            ZK_TRY((launch_pass<SRC_ARRAY, false>(c, a)));
+            ZK_TRY(launch_keys_pass(c, a));
             u64* t = in; in = out; out = t;
         }
         *result = in;
@@ -560,18 +940,25 @@ struct Sorter {
 };
 
 // the instantiated geometries; index = zk_tune(ZK_TUNE_SORT_VARIANT / ZK_TUNE_PAIRS_VARIANT).
-// Measured on MI355X (tools/sortbench.py, 2^30 50-bit keys): 0 -> 3.1 TB/s x 7 passes, 1 -> 2.4,
-// 2 -> 2.9, 3 -> 2.75 x 6 passes (the fastest total).
-typedef Cfg<512, 16, 8> V0;
-typedef Cfg<256, 16, 8> V1;
-typedef Cfg<1024, 16, 8> V2;
-typedef Cfg<512, 16, 9> V3;
+// Measured on MI355X (tools/sortbench.py, 10^9 50-bit keys, per pass of 16 B/key):
+//   0: 8-bit digits, segmented look-back, 7 passes     1: the same with 4096-key tiles
+//   2: 9-bit digits, one serial chain per digit (the first version): 2.75 TB/s x 6 passes
+//   4: 9-bit digits, segmented look-back: 2.85 TB/s
+//   3: 9-bit digits, persistent two-stage pipeline + scanner workgroups for the key passes: 3.07 TB/s (default)
+// Tried in the pipeline and slower: 768x8 and 1024x6/8 threads x keys (2.0-2.3 TB/s: the per-wave digit
+// counters cost as much as the keys), loading the next tile's keys a stage early (spills: 2.87).
+typedef Cfg<512, 16, 8, 1, 4> V0;
+typedef Cfg<256, 16, 8, 1, 4> V1;
+typedef Cfg<512, 16, 9, 1, 4, 0> V2;
+typedef Cfg<512, 16, 9, 1, 4, 32, true> V3;
+typedef Cfg<512, 16, 9, 1, 4, 32> V4;
 #define ZK_SORT_DISPATCH(c, CALL) ZK_SORT_DISPATCH_V((c)->sort_variant, CALL)
 #define ZK_SORT_DISPATCH_V(v, CALL)                 \
     switch (v) {                                    \
         case 0: return Sorter<V0>::CALL;            \
         case 1: return Sorter<V1>::CALL;            \
         case 2: return Sorter<V2>::CALL;            \
+        case 4: return Sorter<V4>::CALL;            \
         default: return Sorter<V3>::CALL;           \
     }
 
@@ -589,7 +976,7 @@ int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n,
 
 // digit width of the geometry used for key arrays (the truncated sort sizes its bit range with it)
 int sort_rbits(zk_ctx* c) {
-    switch (c->sort_variant) { case 0: case 1: case 2: return 8; default: return 9; }
+    switch (c->sort_variant) { case 0: case 1: return 8; default: return 9; }
 }
 
 int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,

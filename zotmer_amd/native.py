@@ -16,7 +16,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzotk.so")
+# ZOTK_LIB: load a differently built libzotk.so (diagnostic builds, tools/stamps.py); same ABI required
+LIB_PATH = os.environ.get("ZOTK_LIB") or os.path.join(_HERE, "libzotk.so")
 
 ZK_OK, ZK_EINVAL, ZK_ENOMEM, ZK_EHIP, ZK_ENOSPC, ZK_EOVERFLOW, ZK_EINTERNAL, ZK_ERANGE = 0, -1, -2, -3, -4, -5, -6, -7
 KMERIZE_CANONICAL, KMERIZE_BOTH, KMERIZE_SUBSAMPLE = 0, 1, 2
