@@ -97,6 +97,11 @@ def main():
         # torch bundles its own HIP runtime: let it load first so that libzotk.so binds to the same
         # copy (same SONAME) instead of dragging a second runtime into the process
         import torch  # noqa: F401
+    # a rebuild (make) or RCCL's version banner may write to stdout; the contract is ONE JSON line there,
+    # so everything but the final print goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
@@ -104,11 +109,6 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    # RCCL may print a version banner on stdout; the contract is ONE JSON line there, so everything
-    # but the final print goes to stderr
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
 
     dist = None
     force_exchange = os.environ.get("ZOT_FORCE_EXCHANGE") == "1"      # rehearse the N > 1 path with one rank

@@ -28,18 +28,31 @@ template <int T> struct TileImage {
     u32 valid[NCH];
 };
 
-__device__ __forceinline__ void encode_chunk16(const u8* __restrict__ stream, u64 n_bytes, u64 off,
-                                               u32& codes, u32& vmask) {
-    u32 w[4] = {0, 0, 0, 0};
+// the 16 stream bytes at `off` (zero past the end), as four little-endian words
+__device__ __forceinline__ uint4 load_chunk16(const u8* __restrict__ stream, u64 n_bytes, u64 off) {
+    uint4 q = make_uint4(0, 0, 0, 0);
     if (off + 16 <= n_bytes) {
-        uint4 q = *reinterpret_cast<const uint4*>(stream + off);
-        w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+        q = *reinterpret_cast<const uint4*>(stream + off);
     } else if (off < n_bytes) {
+        u32 w[4] = {0, 0, 0, 0};
         for (int b = 0; b < 16; b++) {
             u32 c = (off + b < n_bytes) ? stream[off + b] : 0u;
             w[b >> 2] |= c << (8 * (b & 3));
         }
+        q = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    return q;
+}
+
+__device__ __forceinline__ void encode_words16(const uint4 q, u32& codes, u32& vmask);
+
+__device__ __forceinline__ void encode_chunk16(const u8* __restrict__ stream, u64 n_bytes, u64 off,
+                                               u32& codes, u32& vmask) {
+    encode_words16(load_chunk16(stream, n_bytes, off), codes, vmask);
+}
+
+__device__ __forceinline__ void encode_words16(const uint4 q, u32& codes, u32& vmask) {
+    const u32 w[4] = {q.x, q.y, q.z, q.w};
     u32 cc = 0, vv = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -84,6 +97,35 @@ __device__ __forceinline__ bool window_at(const TileImage<T>& img, int p, int K,
                   (u64)img.valid[j + 3];
     const u64 need = (K >= 64) ? ~0ull : ((1ull << K) - 1);
     return ((v << s) >> (64 - K)) == need;
+}
+
+// The 16 windows that start in chunk j (positions 16j .. 16j+15), forward and reverse complement, from
+// eight LDS words instead of eight per window.  With S = the 64 bases from 16j on as a 128-bit number
+// (first base on top) and R = the reverse complement of those 64 bases,
+//     x_i  = (S >> 2(64 - i - K)) & mask        rc(x_i) = (R >> 2i) & mask
+// (K <= 31, so a window never reaches past base 45 of the 64), and window i is valid iff the validity
+// bits i .. i+K-1 are all set, which one "run of K ones" mask answers for all 16.
+// Returns the 16 validity bits (bit i = window i).
+template <int T>
+__device__ __forceinline__ u32 windows16(const TileImage<T>& img, int j, int K, u64 (&x)[16], u64 (&xb)[16]) {
+    const u64 a = ((u64)img.codes[j] << 32) | img.codes[j + 1];
+    const u64 b = ((u64)img.codes[j + 2] << 32) | img.codes[j + 3];
+    const u64 rhi = rev_pairs(~b), rlo = rev_pairs(~a);
+    const u64 mask = ~0ull >> (64 - 2 * K);         // 1 <= K <= 32
+    u64 v = ((u64)img.valid[j] << 48) | ((u64)img.valid[j + 1] << 32) | ((u64)img.valid[j + 2] << 16) | (u64)img.valid[j + 3];
+    int have = 1;                                   // v: bit 63-q = position q; make bit 63-q mean "q .. q+K-1 all valid"
+    while (2 * have <= K) { v &= v << have; have *= 2; }
+    v &= v << (K - have);
+    u32 ok = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int sh = 128 - 2 * i - 2 * K;         // 36 .. 126, uniform
+        const u64 f = (sh >= 64) ? (a >> ((sh - 64) & 63)) : ((a << ((64 - sh) & 63)) | (b >> (sh & 63)));
+        x[i] = f & mask;
+        xb[i] = ((i ? ((rlo >> (2 * i)) | (rhi << (64 - 2 * i))) : rlo)) & mask;
+        ok |= (u32)((v >> (63 - i)) & 1ull) << i;
+    }
+    return ok;
 }
 
 }  // namespace zk

@@ -18,7 +18,7 @@ struct zk_ctx {
     int short_sort = 0;        // zk_kmerize: 1 = sort only the top ~log2(n)+3 bits and finish in the mirror stage (opt-in:
                                // pays off on uncorrelated reads only)
     int side_div = 8;          // ... side list capacity = n / side_div (tests shrink it to force the fallback)
-    int pairs_variant = 3;     // ... for (key, u32) pairs
+    int pairs_variant = 2;     // ... for (key, u32) pairs
 
     // workspace arena: a bump allocator reset at the start of every API call
     char* arena = nullptr;

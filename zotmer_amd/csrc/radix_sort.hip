@@ -154,6 +154,18 @@ __device__ __forceinline__ u32 load_tile(const SortArgs& a, u32 tile, TileImage<
                 live |= (ok ? 1u : 0u) << (i + H);
                 if (COUNT && ok) acgt += (1u << (8 * (u32)(x & 3))) + (1u << (8 * (u32)(xb & 3)));
             }
+        } else if (ITEMS == 16) {
+            // The first pass may take its keys in any order (nothing is ordered yet), so a thread takes 16
+            // CONSECUTIVE windows: 8 LDS words per thread instead of 8 per window, no per-window bit reversal.
+            u64 xs[16], xr[16];
+            const u32 ok16 = windows16(*img, (int)threadIdx.x, K, xs, xr);
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const u64 x = xs[i & 15], xb = xr[i & 15];
+                key[i] = (a.mode == ZK_KEYS_CANONICAL) ? (x < xb ? x : xb) : x;
+                if (COUNT && ((ok16 >> i) & 1u)) acgt += (1u << (8 * (u32)(x & 3))) + (1u << (8 * (u32)(xb & 3)));
+            }
+            live = ok16;
         } else {
 #pragma unroll
             for (int i = 0; i < ITEMS; i++) {
@@ -539,12 +551,55 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_kernel(SortArgs a) {
 #define PSTAMP(t, k) do { } while (0)
 #define PSTAT(t) nullptr
 #endif
+// what a workgroup of the pipeline has in flight for its next tile
+template <class C, int SRC> struct NextTile;
+template <class C> struct NextTile<C, SRC_ARRAY> {
+    u64 key[C::ITEMS];
+    u32 live = 0;
+    __device__ __forceinline__ void issue(const SortArgs& a, u32 t, int tid, int wave, int lane) {
+        const u64 base = (u64)t * C::TILE + (u64)wave * (64 * C::ITEMS) + lane;
+        live = 0;
+#pragma unroll
+        for (int i = 0; i < C::ITEMS; i++) {
+            const u64 idx = base + (u64)i * 64;
+            const bool ok = idx < a.n;
+            key[i] = ok ? a.kin[idx] : 0ull;
+            live |= (ok ? 1u : 0u) << i;
+        }
+    }
+};
+template <class C> struct NextTile<C, SRC_STREAM> {
+    uint4 q0, q1;        // this thread's 16-byte chunk(s) of the tile's stream bytes
+    __device__ __forceinline__ void issue(const SortArgs& a, u32 t, int tid, int wave, int lane) {
+        const u64 t0 = (u64)t * C::TILE;
+        q0 = load_chunk16(a.stream, a.n_bytes, t0 + 16ull * tid);
+        q1 = make_uint4(0, 0, 0, 0);
+        if (tid + C::BLOCK < TileImage<C::TILE>::NCH) q1 = load_chunk16(a.stream, a.n_bytes, t0 + 16ull * (tid + C::BLOCK));
+    }
+};
+
 template <class C>
+struct PipeSmem {
+    u64 exch[C::TILE];              // tile A, grouped by digit, until its offsets are known
+    union {
+        u16 cnt[C::NW][C::RADIX];
+        TileImage<C::TILE> img;     // stream source: the 2-bit image of tile B, dead before cnt is zeroed
+    };
+    u32 digit_off[C::RADIX];
+    u64 gbase[C::RADIX];
+    u32 wsum[C::NW];
+    u32 ticket;
+    u32 total_live;
+};
+
+template <class C, int SRC>
 __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a, u32 tiles) {
     constexpr int BLOCK = C::BLOCK, ITEMS = C::ITEMS, RADIX = C::RADIX, NW = C::NW, DPT = C::DPT, TILE = C::TILE;
     static_assert(C::ROUNDS == 1, "the pipeline parks a whole tile in LDS");
     constexpr int NS = RADIX / 64;          // scanner workgroups: 64 digits each
-    __shared__ PassSmem<C> sm;
+    __shared__ PipeSmem<C> sm;
+    static_assert(sizeof(TileImage<C::TILE>) <= sizeof(u16) * C::NW * C::RADIX, "the tile image lives in the counter area");
+    static_assert(SRC == SRC_ARRAY || (ITEMS == 16 && TileImage<TILE>::NCH <= 2 * BLOCK), "stream source: 16 consecutive windows per thread");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 dmask = (1u << a.bits) - 1u;
     u16* mycnt = sm.cnt[wave];
@@ -613,21 +668,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
     // Software pipeline over the tickets: C's ticket is asked for while B is ranked, an iteration early.
     u32 tB = first - NS;
     bool vB = tB < tiles;
-    u64 keyN[ITEMS];
-    u32 liveN = 0, pending = 0;
-    auto issue_loads = [&](u32 t) {
-        const u64 base = (u64)t * TILE + (u64)wave * (64 * ITEMS) + lane;
-        liveN = 0;
-#pragma unroll
-        for (int i = 0; i < ITEMS; i++) {
-            const u64 idx = base + (u64)i * 64;
-            const bool ok = idx < a.n;
-            keyN[i] = ok ? a.kin[idx] : 0ull;
-            liveN |= (ok ? 1u : 0u) << i;
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++) keyN[i] = 0;
+    NextTile<C, SRC> nx;
+    u32 pending = 0;
+    auto issue_loads = [&](u32 t) { nx.issue(a, t, tid, wave, lane); };
     if (vB) {
         if (tid == 0) pending = atomicAdd(a.ticket, 1u);     // the ticket of the tile AFTER the one being loaded
         issue_loads(tB);
@@ -642,16 +685,37 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
         u32 tC = 0;
         bool vC = false;
         u32 tcB[DPT], dexB[DPT];
+        u32 incB = 0, tsumB = 0;
         u64 rowA[DPT];
 #pragma unroll
         for (int j = 0; j < DPT; j++) { tcB[j] = 0; dexB[j] = 0; rowA[j] = 0; }
 
         if (vB) {
+            if constexpr (SRC == SRC_ARRAY) {
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++) key[i] = keyN[i];
-            live = liveN;
-            for (int d = lane; d < RADIX; d += 64) mycnt[d] = 0;
-            __syncthreads();
+                for (int i = 0; i < ITEMS; i++) key[i] = nx.key[i];
+                live = nx.live;
+            } else {
+                __syncthreads();      // the waves that parked the previous tile are done with the counters (same LDS)
+                u32 cc, vv;
+                encode_words16(nx.q0, cc, vv);
+                sm.img.codes[tid] = cc; sm.img.valid[tid] = vv;
+                if (tid + BLOCK < TileImage<TILE>::NCH) {
+                    encode_words16(nx.q1, cc, vv);
+                    sm.img.codes[tid + BLOCK] = cc; sm.img.valid[tid + BLOCK] = vv;
+                }
+                __syncthreads();
+                u64 xs[16], xr[16];
+                live = windows16(sm.img, tid, a.K, xs, xr);
+#pragma unroll
+                for (int i = 0; i < ITEMS; i++) {
+                    const u64 x = xs[i & 15], xb = xr[i & 15];
+                    key[i] = (a.mode == ZK_KEYS_CANONICAL) ? (x < xb ? x : xb) : x;
+                }
+                __syncthreads();      // the image is dead: its space becomes the counters
+            }
+            // this wave's counters: private to the wave until the scan, so no barrier after zeroing them
+            for (int q = lane; q < RADIX / 8; q += 64) reinterpret_cast<uint4*>(mycnt)[q] = make_uint4(0, 0, 0, 0);
 #ifdef ZK_STAMPS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -707,20 +771,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                 tcB[j] = acc;
                 tsum += acc;
             }
-            const u32 inc = wave_incl_scan_u32(tsum);
-            if (lane == 63) sm.wsum[wave] = inc;
-            __syncthreads();
-            u32 woff = 0;
-            for (int w = 0; w < wave; w++) woff += sm.wsum[w];
-            u32 run = woff + inc - tsum;
-            if (tid == BLOCK - 1) sm.total_live = woff + inc;
-#pragma unroll
-            for (int j = 0; j < DPT; j++) {
-                const int d = tid * DPT + j;
-                dexB[j] = run;
-                if (d < RADIX) sm.digit_off[d] = run;
-                run += tcB[j];
-            }
+            incB = wave_incl_scan_u32(tsum);
+            tsumB = tsum;
+            if (lane == 63) sm.wsum[wave] = incB;     // read after the next barrier
         }
 
         if (vB) PSTAMP(tB, 4);
@@ -746,7 +799,23 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                 }
             }
             PSTAMP(tileA, 5);
-            __syncthreads();
+        }
+        __syncthreads();          // A's offsets and B's per-wave digit sums are visible
+        if (vB) {
+            // ---- exclusive scan over the digits of B ------------------------------------------------
+            u32 woff = 0;
+            for (int w = 0; w < wave; w++) woff += sm.wsum[w];
+            u32 run = woff + incB - tsumB;
+            if (tid == BLOCK - 1) sm.total_live = woff + incB;
+#pragma unroll
+            for (int j = 0; j < DPT; j++) {
+                const int d = tid * DPT + j;
+                dexB[j] = run;
+                if (d < RADIX) sm.digit_off[d] = run;
+                run += tcB[j];
+            }
+        }
+        if (have) {
             PSTAMP(tileA, 6);
 #pragma unroll
             for (int i = 0; i < ITEMS; i++) {
@@ -819,10 +888,11 @@ struct Sorter {
         return ZK_OK;
     }
 
-    // persistent pipelined pass (array source, keys only)
+    // persistent pipelined pass (keys only)
+    template <int SRC>
     static int launch_pipe(zk_ctx* c, SortArgs a) {
       if constexpr (C::PIPE) {
-        const u32 tiles = tiles_for(a, SRC_ARRAY);
+        const u32 tiles = tiles_for(a, SRC);
         if (tiles == 0) return ZK_OK;
         u32 grid = (u32)c->num_cus * 2;
         if (grid > tiles) grid = tiles;
@@ -834,15 +904,15 @@ struct Sorter {
         a.err = c->d_err;
         a.dbg = c->dbg;
         a.dbg2 = c->dbg ? c->dbg + 8ull * tiles : nullptr;
-        prof_begin(c, ZK_PROF_PASS_KEYS, 16 * a.n);
-        hipLaunchKernelGGL((pass_pipe_kernel<C>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
+        prof_begin(c, SRC == SRC_STREAM ? ZK_PROF_PASS_STREAM : ZK_PROF_PASS_KEYS, SRC == SRC_STREAM ? a.n_bytes + 8 * a.n : 16 * a.n);
+        hipLaunchKernelGGL((pass_pipe_kernel<C, SRC>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
         prof_end(c);
         ZK_HIP(c, hipGetLastError());
       }
       return ZK_OK;
     }
     static int launch_keys_pass(zk_ctx* c, const SortArgs& a) {
-        if (C::PIPE) return launch_pipe(c, a);
+        if (C::PIPE) return launch_pipe<SRC_ARRAY>(c, a);
         return launch_pass<SRC_ARRAY, false>(c, a);
     }
 
@@ -926,7 +996,8 @@ struct Sorter {
         if (n == 0) return ZK_OK;
         a.kout = buf_a; a.shift = plan.shift[0]; a.bits = plan.bits[0]; a.ghist = ghist;
         a.n = n;
-        ZK_TRY((launch_pass<SRC_STREAM, false>(c, a)));
+        if (C::PIPE && C::ITEMS == 16 && src.mode != ZK_KEYS_BOTH) ZK_TRY(launch_pipe<SRC_STREAM>(c, a));
+        else ZK_TRY((launch_pass<SRC_STREAM, false>(c, a)));
         u64* in = buf_a; u64* out = buf_b;
         for (int p = 1; p < plan.passes; p++) {
             a.kin = in; a.kout = out; a.shift = plan.shift[p]; a.bits = plan.bits[p];
