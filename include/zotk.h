@@ -63,6 +63,7 @@ int zk_copy(zk_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes);   /* d
 #define ZK_TUNE_SORT_VARIANT 1   /* radix-sort geometry index for key arrays, see radix_sort.hip */
 #define ZK_TUNE_PAIRS_VARIANT 2  /* ... for (key, payload) pairs */
 #define ZK_TUNE_SHORT_SORT 3     /* zk_kmerize: 1 = sort only the top ~log2(n)+3 bits, finish in the mirror stage (default 0) */
+#define ZK_TUNE_XCD_GROUP 5    /* radix-sort pipeline: runs of this many consecutive tiles go to one XCD (0 = off, the default; <= 32) */
 #define ZK_TUNE_SIDE_DIV 4       /* ... side-list capacity = n / value (default 8); overflow falls back to the full sort */
 int zk_tune(zk_ctx* ctx, int what, int value);
 

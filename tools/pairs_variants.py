@@ -10,7 +10,7 @@ cfg = synth.CONFIGS["config2"]
 d = ctx.synth_reads(synth.DEFAULT_SEED, 0, R, 150, genome=cfg["genome"], sub_thr=synth.frac32(cfg["sub"]), n_thr=synth.frac32(cfg["n"]))
 cap = int(R * 151 * 0.35) + (1 << 20)
 ok, oc = ctx.empty(cap, np.uint64), ctx.empty(cap, np.uint32)
-for sv, pv, ss in ((3, 2, 0), (4, 2, 0)):
+for sv, pv, ss in ((3, 2, 0),):
     ctx.tune(sort_variant=sv, pairs_variant=pv, short_sort=ss)
     ctx.kmerize(d, 25, out=(ok, oc))
     ctx.profile(True)

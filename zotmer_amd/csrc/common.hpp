@@ -30,6 +30,9 @@ namespace zk {
 
 __device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
 
+// the XCD this wave runs on: HW_REG_XCC_ID (register 20), bits [3:0]
+__device__ __forceinline__ u32 xcc_id() { return (u32)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 15u; }
+
 // number of set bits of `m` strictly below the calling lane
 __device__ __forceinline__ u32 popc_below(u64 m) {
     return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "internal.hpp"
+#include <vector>
 
 namespace zk {
 
@@ -142,6 +143,30 @@ int check_device_error(zk_ctx* c) {
 
 using namespace zk;
 
+// Which XCDs do the workgroups of a launch land on?  (HW_REG_XCC_ID, MI355X_MICROARCH.md: workgroup dispatch.)
+// The radix-sort pipeline hands runs of consecutive tiles to one XCD so that neighbouring output runs meet in
+// one L2; that is only done when a probe launch sees exactly the ids 0..7, otherwise tiles go out in one order.
+__global__ void xcd_probe_kernel(u32* out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
+}
+static int probe_xcds(zk_ctx* c) {
+    const int nb = 512;
+    u32* d = nullptr;
+    if (hipMalloc((void**)&d, nb * sizeof(u32)) != hipSuccess) return 1;
+    hipLaunchKernelGGL(xcd_probe_kernel, dim3(nb), dim3(64), 0, c->stream, d);
+    std::vector<u32> h(nb, 0);
+    int n = 1;
+    if (hipMemcpyAsync(h.data(), d, nb * sizeof(u32), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+        hipStreamSynchronize(c->stream) == hipSuccess) {
+        u32 seen = 0;
+        bool ok = true;
+        for (u32 v : h) { if (v > 7) ok = false; else seen |= 1u << v; }
+        if (ok && seen == 0xffu) n = 8;
+    }
+    (void)hipFree(d);
+    return n;
+}
+
 static std::string g_create_error = "no context";
 
 #define ZK_CREATE_STEP(call)                                                                      \
@@ -180,6 +205,9 @@ zk_ctx* zk_create(int device, uint64_t workspace_bytes) {
     ZK_CREATE_STEP(hipMalloc((void**)&c->d_scalars, 64 * sizeof(u64)));
     ZK_CREATE_STEP(hipHostMalloc((void**)&c->h_scalars, 64 * sizeof(u64), hipHostMallocDefault));
     ZK_CREATE_STEP(hipMemset(c->d_ticket, 0, sizeof(u32)));
+    ZK_CREATE_STEP(hipMalloc((void**)&c->d_xticket, 8 * 32 * sizeof(u32)));
+    ZK_CREATE_STEP(hipMemset(c->d_xticket, 0, 8 * 32 * sizeof(u32)));
+    c->num_xcd = probe_xcds(c);
     ZK_CREATE_STEP(hipMemset(c->d_err, 0, sizeof(u32)));
     ZK_CREATE_STEP(hipMemset(c->d_scalars, 0, 64 * sizeof(u64)));
     if (workspace_bytes) {
@@ -199,6 +227,7 @@ void zk_destroy(zk_ctx* c) {
     if (c->status) (void)hipFree(c->status);
     if (c->part16) (void)hipFree(c->part16);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
+    if (c->d_xticket) (void)hipFree(c->d_xticket);
     if (c->d_err) (void)hipFree(c->d_err);
     if (c->d_scalars) (void)hipFree(c->d_scalars);
     if (c->h_scalars) (void)hipHostFree(c->h_scalars);
@@ -253,6 +282,11 @@ int zk_tune(zk_ctx* c, int what, int value) {
     if (what == ZK_TUNE_PAIRS_VARIANT) { c->pairs_variant = value; return ZK_OK; }
     if (what == ZK_TUNE_SHORT_SORT) { c->short_sort = value; return ZK_OK; }
     if (what == ZK_TUNE_SIDE_DIV) { c->side_div = value; return ZK_OK; }
+    if (what == ZK_TUNE_XCD_GROUP) {
+        if (value < 0 || value > 32 || (value & (value - 1))) return fail(c, ZK_EINVAL, "xcd group must be 0 or a power of two <= 32");
+        c->xcd_group = value;
+        return ZK_OK;
+    }
     return fail(c, ZK_EINVAL, "unknown tuning knob %d", what);
 }
 

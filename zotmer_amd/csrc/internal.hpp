@@ -37,6 +37,9 @@ struct zk_ctx {
     uint64_t part16_words = 0;
     u32 epoch = 0;
     u32* d_ticket = nullptr;   // monotonically increasing tile ticket
+    u32* d_xticket = nullptr;  // radix sort pipeline: one tile counter per XCD, 128 bytes apart (zeroed per launch)
+    int num_xcd = 1;           // XCDs seen by a probe launch at zk_create (8 on MI355X in SPX mode)
+    int xcd_group = 0;         // consecutive tiles an XCD takes at a time (zk_tune; 0 = one global tile order, the default)
     u32 ticket_base = 0;
 
     u32* d_err = nullptr;      // device error word

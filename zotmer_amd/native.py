@@ -206,7 +206,9 @@ class Context:
     PROF_TAGS = {"hist_stream": 1, "hist_array": 2, "pass_stream": 3, "pass_keys": 4, "pass_pairs": 5, "rle": 6,
                  "union_sum": 7, "select": 8, "mirror": 9, "intersect": 10, "count_hist": 11}
 
-    def tune(self, sort_variant=None, pairs_variant=None, short_sort=None, side_div=None):
+    def tune(self, sort_variant=None, pairs_variant=None, short_sort=None, side_div=None, xcd_group=None):
+        if xcd_group is not None:
+            self._check(self.lib.zk_tune(self.h, 5, int(xcd_group)))
         if short_sort is not None:
             self._check(self.lib.zk_tune(self.h, 3, int(short_sort)))
         if side_div is not None:
