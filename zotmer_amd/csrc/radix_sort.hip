@@ -196,6 +196,33 @@ struct HistArgs {
     u32 tiles;
 };
 
+// what a workgroup of the pipeline has in flight for its next tile
+template <class C, int SRC> struct NextTile;
+template <class C> struct NextTile<C, SRC_ARRAY> {
+    u64 key[C::ITEMS];
+    u32 live = 0;
+    __device__ __forceinline__ void issue(const SortArgs& a, u32 t, int tid, int wave, int lane) {
+        const u64 base = (u64)t * C::TILE + (u64)wave * (64 * C::ITEMS) + lane;
+        live = 0;
+#pragma unroll
+        for (int i = 0; i < C::ITEMS; i++) {
+            const u64 idx = base + (u64)i * 64;
+            const bool ok = idx < a.n;
+            key[i] = ok ? a.kin[idx] : 0ull;
+            live |= (ok ? 1u : 0u) << i;
+        }
+    }
+};
+template <class C> struct NextTile<C, SRC_STREAM> {
+    uint4 q0, q1;        // this thread's 16-byte chunk(s) of the tile's stream bytes
+    __device__ __forceinline__ void issue(const SortArgs& a, u32 t, int tid, int wave, int lane) {
+        const u64 t0 = (u64)t * C::TILE;
+        q0 = load_chunk16(a.stream, a.n_bytes, t0 + 16ull * tid);
+        q1 = make_uint4(0, 0, 0, 0);
+        if (tid + C::BLOCK < TileImage<C::TILE>::NCH) q1 = load_chunk16(a.stream, a.n_bytes, t0 + 16ull * (tid + C::BLOCK));
+    }
+};
+
 template <class C, int SRC>
 __global__ __launch_bounds__(C::BLOCK) void hist_kernel(HistArgs h) {
     __shared__ u32 bins[MAX_PASSES * C::RADIX];
@@ -203,21 +230,67 @@ __global__ __launch_bounds__(C::BLOCK) void hist_kernel(HistArgs h) {
     for (int i = threadIdx.x; i < MAX_PASSES * C::RADIX; i += C::BLOCK) bins[i] = 0;
     u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
     __syncthreads();
+    // stream source, one strand: the 16 bytes this thread stages for the NEXT tile are loaded while the current
+    // tile is counted (two workgroups per CU do not hide a global round trip per tile on their own)
+    constexpr bool PREFETCH = (SRC == SRC_STREAM && C::ITEMS == 16);
+    const bool pre = PREFETCH && h.src.mode != ZK_KEYS_BOTH;
+    NextTile<C, SRC_STREAM> nx;
+    nx.q0 = nx.q1 = make_uint4(0, 0, 0, 0);
+    if (pre && blockIdx.x < h.tiles) nx.issue(h.src, blockIdx.x, threadIdx.x, 0, 0);
     for (u32 tile = blockIdx.x; tile < h.tiles; tile += gridDim.x) {
         u64 key[C::ITEMS];
         u32 val[C::ITEMS];
         u32 pk = 0;
-        u32 live = load_tile<C, SRC, false, SRC == SRC_STREAM>(h.src, tile, &img, key, val, pk);
+        u32 live = 0;
+        if (pre) {
+            if constexpr (PREFETCH) {
+                u32 cc, vv;
+                encode_words16(nx.q0, cc, vv);
+                img.codes[threadIdx.x] = cc; img.valid[threadIdx.x] = vv;
+                if (threadIdx.x + C::BLOCK < TileImage<C::TILE>::NCH) {
+                    encode_words16(nx.q1, cc, vv);
+                    img.codes[threadIdx.x + C::BLOCK] = cc; img.valid[threadIdx.x + C::BLOCK] = vv;
+                }
+                __syncthreads();
+                if (tile + gridDim.x < h.tiles) nx.issue(h.src, tile + gridDim.x, threadIdx.x, 0, 0);
+                u64 xs[16], xr[16];
+                live = windows16(img, (int)threadIdx.x, h.src.K, xs, xr);
+#pragma unroll
+                for (int i = 0; i < C::ITEMS; i++) {
+                    const u64 x = xs[i & 15], xb = xr[i & 15];
+                    key[i] = (h.src.mode == ZK_KEYS_CANONICAL) ? (x < xb ? x : xb) : x;
+                    if ((live >> i) & 1u) pk += (1u << (8 * (u32)(x & 3))) + (1u << (8 * (u32)(xb & 3)));
+                }
+            }
+        } else {
+            live = load_tile<C, SRC, false, SRC == SRC_STREAM>(h.src, tile, &img, key, val, pk);
+        }
         a0 += pk & 0xffu; a1 += (pk >> 8) & 0xffu; a2 += (pk >> 16) & 0xffu; a3 += pk >> 24;
 #pragma unroll
         for (int i = 0; i < C::ITEMS; i++) {
-            if ((live >> i) & 1u) {
+            const bool lv = (live >> i) & 1u;
 #pragma unroll
-                for (int p = 0; p < MAX_PASSES; p++) {
-                    if (p < h.plan.passes) {
-                        const u32 d = (u32)(key[i] >> h.plan.shift[p]) & ((1u << h.plan.bits[p]) - 1u);
-                        atomicAdd(&bins[p * C::RADIX + d], 1u);
+            for (int p = 0; p < MAX_PASSES; p++) {
+                if (p < h.plan.passes) {
+                    const u32 d = (u32)(key[i] >> h.plan.shift[p]) & ((1u << h.plan.bits[p]) - 1u);
+                    bool act = lv;
+                    if (SRC == SRC_ARRAY) {
+                        // 64 consecutive elements of an array often share a digit (sorted or mirrored input: the
+                        // low digits of rc(c) are the leading bases of c), and 64 LDS atomics on one word take 64
+                        // turns.  Peel up to two such groups: their first lane adds the group's size.
+#pragma unroll
+                        for (int r = 0; r < 2; r++) {
+                            const u64 m = __ballot(act);
+                            if (m == 0) break;
+                            const int leader = __ffsll((long long)m) - 1;
+                            const u32 dl = (u32)__builtin_amdgcn_readlane((int)d, leader);
+                            const u64 same = __ballot(act && d == dl);
+                            if (__popcll(same) < 8) break;
+                            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&bins[p * C::RADIX + dl], (u32)__popcll(same));
+                            act = act && d != dl;
+                        }
                     }
+                    if (act) atomicAdd(&bins[p * C::RADIX + d], 1u);
                 }
             }
         }
@@ -591,33 +664,6 @@ __device__ __forceinline__ u32 steal_tile(const SortArgs& a, u32 x, u32 tiles) {
     }
     return 0xffffffffu;
 }
-
-// what a workgroup of the pipeline has in flight for its next tile
-template <class C, int SRC> struct NextTile;
-template <class C> struct NextTile<C, SRC_ARRAY> {
-    u64 key[C::ITEMS];
-    u32 live = 0;
-    __device__ __forceinline__ void issue(const SortArgs& a, u32 t, int tid, int wave, int lane) {
-        const u64 base = (u64)t * C::TILE + (u64)wave * (64 * C::ITEMS) + lane;
-        live = 0;
-#pragma unroll
-        for (int i = 0; i < C::ITEMS; i++) {
-            const u64 idx = base + (u64)i * 64;
-            const bool ok = idx < a.n;
-            key[i] = ok ? a.kin[idx] : 0ull;
-            live |= (ok ? 1u : 0u) << i;
-        }
-    }
-};
-template <class C> struct NextTile<C, SRC_STREAM> {
-    uint4 q0, q1;        // this thread's 16-byte chunk(s) of the tile's stream bytes
-    __device__ __forceinline__ void issue(const SortArgs& a, u32 t, int tid, int wave, int lane) {
-        const u64 t0 = (u64)t * C::TILE;
-        q0 = load_chunk16(a.stream, a.n_bytes, t0 + 16ull * tid);
-        q1 = make_uint4(0, 0, 0, 0);
-        if (tid + C::BLOCK < TileImage<C::TILE>::NCH) q1 = load_chunk16(a.stream, a.n_bytes, t0 + 16ull * (tid + C::BLOCK));
-    }
-};
 
 template <class C>
 struct PipeSmem {
