@@ -93,6 +93,8 @@ static inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; 
 int sort_workspace_bytes(uint64_t n, bool pairs, uint64_t* bytes);
 int sort_keys(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** result);
 int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, u64** rk, u32** rv);
+int sort_pairs_mirrored(zk_ctx* c, const u64* src_k, const u32* src_v, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int K,
+                        u64** rk, u32** rv);
 // sort whose first pass generates the keys from a base stream (encode.hip + radix_sort.hip)
 struct StreamSrc { const u8* stream; uint64_t n_bytes; int K; int mode; int lo_bit; };   // mode: ZK_KEYS_*; sort bits [lo_bit, 2K)
 int sort_rbits(zk_ctx* c);

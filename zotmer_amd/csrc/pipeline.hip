@@ -85,12 +85,10 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     ZK_TRY(aux_require(c, 2 * a8 + 2 * a4, &aux));
     u64* rk = (u64*)aux; u64* rk2 = (u64*)(aux + a8);
     u32* rv = (u32*)(aux + 2 * a8); u32* rv2 = (u32*)(aux + 2 * a8 + a4);
-    prof_begin(c, ZK_PROF_MIRROR, 24 * uc);
-    hipLaunchKernelGGL(mirror_kernel, dim3(ew_grid(c, uc)), dim3(256), 0, c->stream, sorted, cnt, (u64)uc, K, rk, rv);
-    prof_end(c);
-    ZK_HIP(c, hipGetLastError());
+    // the mirrored pairs (rc c, n) are never written unsorted: the histogram and the first pass of their sort
+    // read (c, n) and reverse-complement on load
     u64* sk; u32* sv;
-    ZK_TRY(sort_pairs(c, rk, rk2, rv, rv2, uc, 2 * K, &sk, &sv));
+    ZK_TRY(sort_pairs_mirrored(c, sorted, cnt, rk, rk2, rv, rv2, uc, K, &sk, &sv));
     return union_sum(c, sorted, cnt, uc, sk, sv, uc, out_k, out_c, 32, cap, n_out, nullptr);
 }
 

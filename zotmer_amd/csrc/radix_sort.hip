@@ -76,6 +76,7 @@ struct SortArgs {
     const u64* kin;
     const u32* vin;
     u64 n;
+    int mirror_K;       // > 0: the key is rc(kin[i]) for this K (first pass and histogram of the mirror sort)
     // stream source
     const u8* stream;
     u64 n_bytes;
@@ -129,6 +130,10 @@ __device__ __forceinline__ u32 load_tile(const SortArgs& a, u32 tile, TileImage<
             key[i] = ok ? a.kin[idx] : 0ull;
             if (PAIRS) val[i] = ok ? a.vin[idx] : 0u;
             live |= (ok ? 1u : 0u) << i;
+        }
+        if (a.mirror_K > 0) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) key[i] = revcomp(a.mirror_K, key[i]);
         }
     } else {
         const bool both = (a.mode == ZK_KEYS_BOTH);
@@ -1061,22 +1066,28 @@ struct Sorter {
         return ZK_OK;
     }
 
-    static int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, u64** rk, u32** rv) {
+    // mirror_K > 0: sort (rc(src_k[i]), src_v[i]) instead, without writing the mirrored keys first: the histogram and
+    // the first pass apply rc on load; src_k / src_v are only read, keys/alt/vals/valt are the two work buffers.
+    static int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, u64** rk, u32** rv,
+                          const u64* src_k = nullptr, const u32* src_v = nullptr, int mirror_K = 0) {
         PassPlan plan = make_plan(key_bits, C::RBITS);
         u64* ghist;
         ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * C::RADIX, (void**)&ghist));
         SortArgs a = {};
-        a.kin = keys; a.n = n;
+        a.kin = mirror_K ? src_k : keys; a.n = n; a.mirror_K = mirror_K;
         ZK_TRY(launch_hist<SRC_ARRAY>(c, a, plan, ghist, nullptr, c->d_scalars + 8));
-        u64* in = keys; u64* out = alt; u32* vi = vals; u32* vo = valt;
+        const u64* in = mirror_K ? src_k : keys; const u32* vi = mirror_K ? src_v : vals;
+        u64* out = mirror_K ? keys : alt; u32* vo = mirror_K ? vals : valt;
         for (int p = 0; p < plan.passes; p++) {
             a.kin = in; a.kout = out; a.vin = vi; a.vout = vo; a.shift = plan.shift[p]; a.bits = plan.bits[p];
             a.ghist = ghist + p * C::RADIX;
+            a.mirror_K = (p == 0) ? mirror_K : 0;
             ZK_TRY((launch_pass<SRC_ARRAY, true>(c, a)));
-            u64* t = in; in = out; out = t;
-            u32* tv = vi; vi = vo; vo = tv;
+            in = out; vi = vo;
+            out = (out == keys) ? alt : keys;
+            vo = (vo == vals) ? valt : vals;
         }
-        *rk = in; *rv = vi;
+        *rk = const_cast<u64*>(in); *rv = const_cast<u32*>(vi);
         return ZK_OK;
     }
 
@@ -1149,6 +1160,14 @@ int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n,
     *rk = keys; *rv = vals;
     if (n == 0) return ZK_OK;
     ZK_SORT_DISPATCH_V(c->pairs_variant, sort_pairs(c, keys, alt, vals, valt, n, key_bits, rk, rv));
+}
+
+// (rc(src_k[i]), src_v[i]) sorted by key; keys/alt/vals/valt are work buffers, the source arrays are only read
+int sort_pairs_mirrored(zk_ctx* c, const u64* src_k, const u32* src_v, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int K,
+                        u64** rk, u32** rv) {
+    *rk = keys; *rv = vals;
+    if (n == 0) return ZK_OK;
+    ZK_SORT_DISPATCH_V(c->pairs_variant, sort_pairs(c, keys, alt, vals, valt, n, 2 * K, rk, rv, src_k, src_v, K));
 }
 
 // digit width of the geometry used for key arrays (the truncated sort sizes its bit range with it)
