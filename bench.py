@@ -41,11 +41,11 @@ def model_bytes(n_stream_bytes, instances, unique, K):
 
 def measured_traffic(kernel_substr, n_keys_now):
     """HBM bytes per launch of the dominant kernel from the committed PMC runs of THIS command
-    (profiles/r01_config2_final/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    (profiles/r01_config2_pipeline/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     passes, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950; tools/collect_traffic.py).  PMC
     counters cannot be read from inside the timed run, so the figure is taken from that profile and only
     reported when the workload (number of keys per launch) is the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_config2_final", "pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_config2_pipeline", "pmc_traffic.json")
     try:
         d = json.load(open(path))
     except Exception:
@@ -210,11 +210,11 @@ def main():
                        "reads_per_gpu": R, "read_len": L, "K": K, "genome": cfg["genome"], "seed": seed,
                        "strategy": "both-strands" if a.both else "canonical+mirror",
                        "parallelism": "1 gpu" if world == 1 else "reads sharded over %d gpus + value-range all-to-all" % world},
-            "roofline": {"bound": "hbm", "kernel": "pass_kernel<array,keys> (one LSD radix pass, 16 B/key)",
+            "roofline": {"bound": "hbm", "kernel": "pass_pipe_kernel<array,keys> (one LSD radix pass of 64-bit keys, 16 B/key, persistent two-stage pipeline)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("pass_kernel<zk::Cfg<512, 16, 9>, 0, false>", st.n_windows),
+                         "traffic": measured_traffic("pass_pipe_kernel<zk::Cfg<512, 16, 9, 1, 4, 32, true>, 0>", st.n_windows),
                          "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, KiB) of this "
-                                         "command, profiles/r01_config2_final/pmc_traffic.json; null if the workload differs",
+                                         "command, profiles/r01_config2_pipeline/pmc_traffic.json; null if the workload differs",
                          "launches": pk["launches"],
                          "avg_launch_ms": pk["ms"] / pk["launches"] if pk["launches"] else None},
             "pipeline": {"windows_per_s": value * 1e9 / 2, "instances_per_step": st.n_instances, "unique": st.n_unique,

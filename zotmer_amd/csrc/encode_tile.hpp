@@ -128,4 +128,31 @@ __device__ __forceinline__ u32 windows16(const TileImage<T>& img, int j, int K, 
     return ok;
 }
 
+// The same, one window at a time, for a consumer that does not keep the 16 keys (the digit histogram):
+// eight registers of state instead of sixty-four of results.
+template <int T>
+struct Windows16 {
+    u64 a, b, rlo, rhi, v, mask;
+    int K;
+    __device__ __forceinline__ void init(const TileImage<T>& img, int j, int K_) {
+        K = K_;
+        a = ((u64)img.codes[j] << 32) | img.codes[j + 1];
+        b = ((u64)img.codes[j + 2] << 32) | img.codes[j + 3];
+        rhi = rev_pairs(~b); rlo = rev_pairs(~a);
+        mask = ~0ull >> (64 - 2 * K);
+        v = ((u64)img.valid[j] << 48) | ((u64)img.valid[j + 1] << 32) | ((u64)img.valid[j + 2] << 16) | (u64)img.valid[j + 3];
+        int have = 1;
+        while (2 * have <= K) { v &= v << have; have *= 2; }
+        v &= v << (K - have);
+    }
+    // i is a compile-time constant at every call site (unrolled loops)
+    __device__ __forceinline__ bool get(int i, u64& x, u64& xb) const {
+        const int sh = 128 - 2 * i - 2 * K;
+        const u64 f = (sh >= 64) ? (a >> ((sh - 64) & 63)) : ((a << ((64 - sh) & 63)) | (b >> (sh & 63)));
+        x = f & mask;
+        xb = (i ? ((rlo >> ((2 * i) & 63)) | (rhi << ((64 - 2 * i) & 63))) : rlo) & mask;
+        return (v >> (63 - i)) & 1ull;
+    }
+};
+
 }  // namespace zk

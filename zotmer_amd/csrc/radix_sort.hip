@@ -208,6 +208,14 @@ template <class C> struct NextTile<C, SRC_ARRAY> {
     u32 live = 0;
     __device__ __forceinline__ void issue(const SortArgs& a, u32 t, int tid, int wave, int lane) {
         const u64 base = (u64)t * C::TILE + (u64)wave * (64 * C::ITEMS) + lane;
+        if ((u64)(t + 1) * C::TILE <= a.n) {
+            // a whole tile (all but the last): one address, constant offsets, no per-key bound checks
+            const u64* p = a.kin + base;
+#pragma unroll
+            for (int i = 0; i < C::ITEMS; i++) key[i] = p[i * 64];
+            live = (C::ITEMS >= 32) ? ~0u : ((1u << C::ITEMS) - 1u);
+            return;
+        }
         live = 0;
 #pragma unroll
         for (int i = 0; i < C::ITEMS; i++) {
@@ -229,7 +237,7 @@ template <class C> struct NextTile<C, SRC_STREAM> {
 };
 
 template <class C, int SRC>
-__global__ __launch_bounds__(C::BLOCK) void hist_kernel(HistArgs h) {
+__global__ __launch_bounds__(C::BLOCK, (SRC == SRC_STREAM && C::BLOCK <= 512) ? 8 : 1) void hist_kernel(HistArgs h) {
     __shared__ u32 bins[MAX_PASSES * C::RADIX];
     __shared__ TileImage<C::TILE> img;
     for (int i = threadIdx.x; i < MAX_PASSES * C::RADIX; i += C::BLOCK) bins[i] = 0;
@@ -258,14 +266,25 @@ __global__ __launch_bounds__(C::BLOCK) void hist_kernel(HistArgs h) {
                 }
                 __syncthreads();
                 if (tile + gridDim.x < h.tiles) nx.issue(h.src, tile + gridDim.x, threadIdx.x, 0, 0);
-                u64 xs[16], xr[16];
-                live = windows16(img, (int)threadIdx.x, h.src.K, xs, xr);
+                // keys are counted as they are made, never kept: few registers, many waves per SIMD
+                Windows16<C::TILE> wg;
+                wg.init(img, (int)threadIdx.x, h.src.K);
 #pragma unroll
-                for (int i = 0; i < C::ITEMS; i++) {
-                    const u64 x = xs[i & 15], xb = xr[i & 15];
-                    key[i] = (h.src.mode == ZK_KEYS_CANONICAL) ? (x < xb ? x : xb) : x;
-                    if ((live >> i) & 1u) pk += (1u << (8 * (u32)(x & 3))) + (1u << (8 * (u32)(xb & 3)));
+                for (int i = 0; i < 16; i++) {
+                    u64 x, xb;
+                    if (wg.get(i, x, xb)) {
+                        pk += (1u << (8 * (u32)(x & 3))) + (1u << (8 * (u32)(xb & 3)));
+                        const u64 kk = (h.src.mode == ZK_KEYS_CANONICAL) ? (x < xb ? x : xb) : x;
+#pragma unroll
+                        for (int p = 0; p < MAX_PASSES; p++) {
+                            if (p < h.plan.passes) {
+                                const u32 d = (u32)(kk >> h.plan.shift[p]) & ((1u << h.plan.bits[p]) - 1u);
+                                atomicAdd(&bins[p * C::RADIX + d], 1u);
+                            }
+                        }
+                    }
                 }
+                live = 0;         // nothing left for the generic counting loop below
             }
         } else {
             live = load_tile<C, SRC, false, SRC == SRC_STREAM>(h.src, tile, &img, key, val, pk);
@@ -672,10 +691,11 @@ __device__ __forceinline__ u32 steal_tile(const SortArgs& a, u32 x, u32 tiles) {
 
 template <class C>
 struct PipeSmem {
+    static constexpr bool IMG_FITS = sizeof(TileImage<C::TILE>) <= sizeof(u16) * C::NW * C::RADIX;
     u64 exch[C::TILE];              // tile A, grouped by digit, until its offsets are known
     union {
         u16 cnt[C::NW][C::RADIX];
-        TileImage<C::TILE> img;     // stream source: the 2-bit image of tile B, dead before cnt is zeroed
+        TileImage<PipeSmem::IMG_FITS ? C::TILE : 16> img;     // stream source: the 2-bit image of tile B, dead before cnt is zeroed
     };
     u32 digit_off[C::RADIX];
     u64 gbase[C::RADIX];
@@ -690,7 +710,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
     static_assert(C::ROUNDS == 1, "the pipeline parks a whole tile in LDS");
     constexpr int NS = RADIX / 64;          // scanner workgroups: 64 digits each
     __shared__ PipeSmem<C> sm;
-    static_assert(sizeof(TileImage<C::TILE>) <= sizeof(u16) * C::NW * C::RADIX, "the tile image lives in the counter area");
+    static_assert(SRC == SRC_ARRAY || sizeof(TileImage<C::TILE>) <= sizeof(u16) * C::NW * C::RADIX, "the tile image lives in the counter area");
     static_assert(SRC == SRC_ARRAY || (ITEMS == 16 && TileImage<TILE>::NCH <= 2 * BLOCK), "stream source: 16 consecutive windows per thread");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 dmask = (1u << a.bits) - 1u;
@@ -872,8 +892,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                         acc += t;
                     }
                 }
-                static_assert(DPT == 1 && BLOCK == RADIX, "one digit per thread in the pipeline");
-                publish_counts16(a.part + (u64)tB * RADIX, d, acc, lane);
+                static_assert(DPT == 1 && BLOCK >= RADIX && RADIX % 64 == 0, "one digit per thread in the pipeline");
+                if (wave * 64 < RADIX) publish_counts16(a.part + (u64)tB * RADIX, d, acc, lane);     // whole waves
                 tcB[j] = acc;
                 tsum += acc;
             }
@@ -923,14 +943,24 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
         }
         if (have) {
             PSTAMP(tileA, 6);
+            // The slot index is made opaque: otherwise the compiler precomputes the sixteen `kout + slot` addresses
+            // outside the tile loop, spills them, and every store then waits (vmcnt is in order) for the reload
+            // of its address and with it for the store before it -- sixteen serial round trips per tile.
+            u32 slot0 = (u32)tid;
+            asm volatile("" : "+v"(slot0));
+            // eight slots at a time: the LDS reads of a group are independent of each other (slots past the live
+            // count hold stale but readable keys), only the global store is predicated
+            constexpr int G = 4;
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++) {
-                const u32 sl = tid + i * BLOCK;
-                if (sl < totalA) {
-                    const u64 k = sm.exch[sl];
-                    const u32 d = (u32)(k >> a.shift) & dmask;
-                    a.kout[sm.gbase[d] + sl] = k;
-                }
+            for (int i0 = 0; i0 < ITEMS; i0 += G) {
+                u64 kk[G], pos[G];
+#pragma unroll
+                for (int g = 0; g < G; g++) kk[g] = sm.exch[slot0 + (i0 + g) * BLOCK];
+#pragma unroll
+                for (int g = 0; g < G; g++) pos[g] = sm.gbase[(u32)(kk[g] >> a.shift) & dmask] + (slot0 + (i0 + g) * BLOCK);
+#pragma unroll
+                for (int g = 0; g < G; g++)
+                    if (slot0 + (i0 + g) * BLOCK < totalA) a.kout[pos[g]] = kk[g];
             }
         }
 #ifdef ZK_STAMPS
@@ -1113,8 +1143,12 @@ struct Sorter {
         if (n == 0) return ZK_OK;
         a.kout = buf_a; a.shift = plan.shift[0]; a.bits = plan.bits[0]; a.ghist = ghist;
         a.n = n;
-        if (C::PIPE && C::ITEMS == 16 && src.mode != ZK_KEYS_BOTH) ZK_TRY(launch_pipe<SRC_STREAM>(c, a));
-        else ZK_TRY((launch_pass<SRC_STREAM, false>(c, a)));
+        if constexpr (C::PIPE && C::ITEMS == 16 && PipeSmem<C>::IMG_FITS) {
+            if (src.mode != ZK_KEYS_BOTH) ZK_TRY(launch_pipe<SRC_STREAM>(c, a));
+            else ZK_TRY((launch_pass<SRC_STREAM, false>(c, a)));
+        } else {
+            ZK_TRY((launch_pass<SRC_STREAM, false>(c, a)));
+        }
         u64* in = buf_a; u64* out = buf_b;
         for (int p = 1; p < plan.passes; p++) {
             a.kin = in; a.kout = out; a.shift = plan.shift[p]; a.bits = plan.bits[p];
@@ -1140,6 +1174,7 @@ typedef Cfg<256, 16, 8, 1, 4> V1;
 typedef Cfg<512, 16, 9, 1, 4, 0> V2;
 typedef Cfg<512, 16, 9, 1, 4, 32, true> V3;
 typedef Cfg<512, 16, 9, 1, 4, 32> V4;
+typedef Cfg<512, 16, 8, 1, 4, 32, true> V5;      // the pipeline with 8-bit digits: 256-byte runs, 7 passes
 #define ZK_SORT_DISPATCH(c, CALL) ZK_SORT_DISPATCH_V((c)->sort_variant, CALL)
 #define ZK_SORT_DISPATCH_V(v, CALL)                 \
     switch (v) {                                    \
@@ -1147,6 +1182,7 @@ typedef Cfg<512, 16, 9, 1, 4, 32> V4;
         case 1: return Sorter<V1>::CALL;            \
         case 2: return Sorter<V2>::CALL;            \
         case 4: return Sorter<V4>::CALL;            \
+        case 5: return Sorter<V5>::CALL;            \
         default: return Sorter<V3>::CALL;           \
     }
 
@@ -1172,7 +1208,7 @@ int sort_pairs_mirrored(zk_ctx* c, const u64* src_k, const u32* src_v, u64* keys
 
 // digit width of the geometry used for key arrays (the truncated sort sizes its bit range with it)
 int sort_rbits(zk_ctx* c) {
-    switch (c->sort_variant) { case 0: case 1: return 8; default: return 9; }
+    switch (c->sort_variant) { case 0: case 1: case 5: return 8; default: return 9; }
 }
 
 int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,

@@ -767,12 +767,30 @@ __global__ __launch_bounds__(256) void count_hist_kernel(const CT* __restrict__ 
     __shared__ u32 bins[HIST_DENSE];
     for (int i = threadIdx.x; i < HIST_DENSE; i += 256) bins[i] = 0;
     __syncthreads();
-    for (u64 i = (u64)blockIdx.x * 256 + threadIdx.x; i < n; i += (u64)gridDim.x * 256) {
-        const u64 v = counts[i];
-        if (v < HIST_DENSE) atomicAdd(&bins[v], 1u);
-        else {
-            const u64 slot = atomicAdd(big_n, 1ull);
-            if (slot < big_cap) big[slot] = v;
+    // Counts are few distinct values (most k-mers of a sequencing run occur once, the rest near the coverage), and 64
+    // LDS atomics on one word take 64 turns: peel the two commonest values of the wave, their first lane adds the lot.
+    const u64 step = (u64)gridDim.x * 256;
+    for (u64 i0 = (u64)blockIdx.x * 256; i0 < n; i0 += step) {      // uniform trip count: every lane reaches the ballots
+        const u64 i = i0 + threadIdx.x;
+        bool act = i < n;
+        const u64 v = act ? (u64)counts[i] : 0ull;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const u64 m = __ballot(act && v < HIST_DENSE);
+            if (m == 0) break;
+            const int leader = __ffsll((long long)m) - 1;
+            const u32 vl = (u32)__builtin_amdgcn_readlane((int)(u32)v, leader);
+            const u64 same = __ballot(act && v == (u64)vl);
+            if (__popcll(same) < 8) break;
+            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&bins[vl], (u32)__popcll(same));
+            act = act && v != (u64)vl;
+        }
+        if (act) {
+            if (v < HIST_DENSE) atomicAdd(&bins[v], 1u);
+            else {
+                const u64 slot = atomicAdd(big_n, 1ull);
+                if (slot < big_cap) big[slot] = v;
+            }
         }
     }
     __syncthreads();
