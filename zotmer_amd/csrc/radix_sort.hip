@@ -619,16 +619,19 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_kernel(SortArgs a) {
             if (lpos[i] - lo < (u32)EXCH) sm.exch[lpos[i] - lo] = key[i];
         __syncthreads();
         u64 gpos[IPR];
+        // four slots at a time: their LDS reads are independent (slots past the live count hold stale but readable
+        // keys); only the global store is predicated
+        constexpr int G = (IPR % 4 == 0) ? 4 : 1;
 #pragma unroll
-        for (int i = 0; i < IPR; i++) {
-            const u32 s = tid + i * BLOCK;
-            gpos[i] = ~0ull;
-            if (lo + s < total) {
-                const u64 k = sm.exch[s];
-                const u32 d = (u32)(k >> a.shift) & dmask;
-                gpos[i] = sm.gbase[d] + lo + s;
-                a.kout[gpos[i]] = k;
-            }
+        for (int i0 = 0; i0 < IPR; i0 += G) {
+            u64 kk[G];
+#pragma unroll
+            for (int g = 0; g < G; g++) kk[g] = sm.exch[tid + (i0 + g) * BLOCK];
+#pragma unroll
+            for (int g = 0; g < G; g++) gpos[i0 + g] = sm.gbase[(u32)(kk[g] >> a.shift) & dmask] + lo + (tid + (i0 + g) * BLOCK);
+#pragma unroll
+            for (int g = 0; g < G; g++)
+                if (lo + tid + (i0 + g) * BLOCK < total) a.kout[gpos[i0 + g]] = kk[g];
         }
         if (PAIRS) {
             __syncthreads();
