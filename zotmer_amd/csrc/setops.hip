@@ -43,10 +43,13 @@ template <typename CT>
 struct MergeSmem {
     union {
         struct {
-            u64 ka[MRG_TILE + 2];   // [0] = left halo A[a0-1]
-            u64 kb[MRG_TILE + 2];   // [nBt] = right halo B[b1]
-            CT ca[MRG_TILE + 2];
-            CT cb[MRG_TILE + 2];
+            // The A slice and the B slice of a tile add up to MRG_TILE elements, so they share one buffer:
+            //   ka = keys      : [0] = left halo A[a0-1], [1 .. nAt] = the A slice, [nAt+1] = a spare slot that is read
+            //                    (never used) when the A cursor stands at its end
+            //   kb = keys+nAt+2: [0 .. nBt-1] = the B slice, [nBt] = right halo B[b1]
+            // Half the LDS of two full-size buffers: six workgroups per CU instead of three.
+            u64 keys[MRG_TILE + 4];
+            CT cnts[MRG_TILE + 4];
         } in;
         struct {
             u64 k[MRG_TILE];
@@ -78,16 +81,20 @@ __global__ __launch_bounds__(MRG_BLOCK) void union_sum_kernel(const u64* __restr
     const u64 b0 = d0 - a0, b1 = d1 - a1;
     const int nAt = (int)(a1 - a0), nBt = (int)(b1 - b0);
 
+    u64* const ka = sm.in.keys;
+    u64* const kb = sm.in.keys + nAt + 2;
+    CT* const ca = sm.in.cnts;
+    CT* const cb = sm.in.cnts + nAt + 2;
     // stage: ka[1 + i] = A[a0 + i], ka[0] = A[a0 - 1]; kb[j] = B[b0 + j], kb[nBt] = B[b1]
     for (int i = tid; i < nAt + 1; i += MRG_BLOCK) {
         const u64 g = a0 + i;           // element index + 1
-        sm.in.ka[i] = (g >= 1) ? A[g - 1] : 0ull;
-        sm.in.ca[i] = (g >= 1) ? cA[g - 1] : (CT)0;
+        ka[i] = (g >= 1) ? A[g - 1] : 0ull;
+        ca[i] = (g >= 1) ? cA[g - 1] : (CT)0;
     }
     for (int j = tid; j < nBt + 1; j += MRG_BLOCK) {
         const u64 g = b0 + j;
-        sm.in.kb[j] = (g < nB) ? B[g] : 0ull;
-        sm.in.cb[j] = (g < nB) ? cB[g] : (CT)0;
+        kb[j] = (g < nB) ? B[g] : 0ull;
+        cb[j] = (g < nB) ? cB[g] : (CT)0;
     }
     __syncthreads();
     const bool have_left = a0 > 0;
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void union_sum_kernel(const u64* __restr
     int lo = d > nBt ? d - nBt : 0, hi = d < nAt ? d : nAt;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (sm.in.ka[1 + mid] <= sm.in.kb[d - mid - 1]) lo = mid + 1; else hi = mid;
+        if (ka[1 + mid] <= kb[d - mid - 1]) lo = mid + 1; else hi = mid;
     }
     int i = lo, j = d - lo;
     u64 rk[MRG_ITEMS];
@@ -111,14 +118,14 @@ __global__ __launch_bounds__(MRG_BLOCK) void union_sum_kernel(const u64* __restr
         rk[s] = 0; rc[s] = 0;
         if (d + s < total) {
             const bool hasA = i < nAt, hasB = j < nBt;
-            const u64 ak = sm.in.ka[1 + i], bk = sm.in.kb[j];
+            const u64 ak = ka[1 + i], bk = kb[j];
             if (hasA && (!hasB || ak <= bk)) {
                 // the equal partner, if any, is the B cursor (possibly the right halo)
                 const bool bvalid = (j < nBt) || have_right;
-                CT c = sm.in.ca[1 + i];
+                CT c = ca[1 + i];
                 if (MODE == 0) {
                     if (bvalid && bk == ak) {
-                        const CT c2 = c + sm.in.cb[j];
+                        const CT c2 = c + cb[j];
                         if (c2 < c) atomicOr(st.err, ZK_DERR_COUNT_OVERFLOW);
                         c = c2;
                     }
@@ -128,8 +135,8 @@ __global__ __launch_bounds__(MRG_BLOCK) void union_sum_kernel(const u64* __restr
             } else {
                 // dropped when the A element just before it (possibly the left halo) is equal
                 const bool avalid = (i > 0) || have_left;
-                const bool dup = avalid && sm.in.ka[i] == bk;
-                rk[s] = bk; rc[s] = sm.in.cb[j];
+                const bool dup = avalid && ka[i] == bk;
+                rk[s] = bk; rc[s] = cb[j];
                 if (MODE == 0 ? !dup : dup) keep |= 1u << s;
                 j++;
             }
