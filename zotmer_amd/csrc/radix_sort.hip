@@ -734,26 +734,37 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
         u64* carry = sm.exch;                       // [64]: batch number << 40 | running total
         if (tid < 64) carry[tid] = 0;
         __syncthreads();
-        const int d = (int)first * 64 + lane;
-        const u16* src = a.part + d;
-        u64* dst = a.status + d;
+        // Buffer addressing: the batch's base in SGPRs, the lane's offset in one VGPR, the tile's offset as a scalar --
+        // no 64-bit address per load or store in the vector registers (64 of each would not fit).  The buffer range
+        // check is not relied on: every access is predicated on the tile index.
+        const u64 tag = st_pack(ZK_ST_INCLUSIVE, a.epoch, 0);
         const u32 batches = (tiles + U - 1) / U;
         for (u32 b = (u32)wave; b < batches; b += NW) {
             const u32 t0 = b * U;
+            const u32 nt = (tiles - t0 < (u32)U) ? tiles - t0 : (u32)U;
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.part + (u64)t0 * RADIX + (u64)first * 64), 0, 0x7fffffff, 0x00020000);
+            __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.status + (u64)t0 * RADIX + (u64)first * 64), 0, 0x7fffffff, 0x00020000);
             u16 x[U];
 #pragma unroll
-            for (int k = 0; k < U; k++) x[k] = (t0 + k < tiles) ? ld_agent16(src + (u64)(t0 + k) * RADIX) : (u16)0x8000u;
+            for (int k = 0; k < U; k++)
+                x[k] = ((u32)k < nt) ? (u16)__builtin_amdgcn_raw_buffer_load_b16(rs, 2 * lane, k * RADIX * 2, 16) : (u16)0x8000u;
+            // counts that were not published yet are asked for again TOGETHER: one round trip per retry, not one per
+            // missing word (the scanner runs close behind the tiles, so first reads often come back empty)
+            for (int spins = 0;; spins++) {
+                u32 all = 0x8000u;
+#pragma unroll
+                for (int k = 0; k < U; k++) all &= x[k];
+                if (all & 0x8000u) break;
+                if (spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT); break; }
+                __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+                for (int k = 0; k < U; k++)
+                    if (!(x[k] & 0x8000u)) x[k] = (u16)__builtin_amdgcn_raw_buffer_load_b16(rs, 2 * lane, k * RADIX * 2, 16);
+            }
             u32 sum = 0;
 #pragma unroll
             for (int k = 0; k < U; k++) {
-                u16 v = x[k];
-                int spins = 0;
-                while (!(v & 0x8000u)) {
-                    if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT); break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    v = ld_agent16(src + (u64)(t0 + k) * RADIX);
-                }
-                x[k] = v & 0x7fffu;
+                x[k] &= 0x7fffu;
                 sum += x[k];
             }
             // hand-off: wait for batch b-1's total
@@ -767,9 +778,14 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
             }
             u64 run = cv & ((1ull << 40) - 1);
             *cw = ((u64)(b + 1) << 40) | (run + sum);
+            run |= tag;                              // totals stay below 2^40, the tag sits above: plain adds keep it
 #pragma unroll
             for (int k = 0; k < U; k++) {
-                if (t0 + k < tiles) st_agent(dst + (u64)(t0 + k) * RADIX, st_pack(ZK_ST_INCLUSIVE, a.epoch, run));
+                if ((u32)k < nt) {
+                    typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+                    u32x2 w = {(u32)run, (u32)(run >> 32)};
+                    __builtin_amdgcn_raw_buffer_store_b64(w, rd, 8 * lane, k * RADIX * 8, 16);
+                }
                 run += x[k];
             }
         }
@@ -802,7 +818,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
 
     for (;;) {
         if (!vB && !have) break;
-        PSTAMP(tB, 0);
+        if (vB) PSTAMP(tB, 0);
         u64 key[ITEMS];
         u32 rank2[ITEMS / 2];          // two 16-bit ranks per register
         u32 live = 0;
