@@ -59,7 +59,7 @@ def _reads(rank):
     return synth.read_strings(synth.DEFAULT_SEED, rank * READS_PER_RANK, READS_PER_RANK, 150, **KW)
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, chunk=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -69,6 +69,8 @@ def _worker(rank, world, port, outdir):
         kt = torch.from_numpy(local["kmers"].view(np.int64).copy())
         ct = torch.from_numpy(local["counts"].view(np.int32).copy())
         ex = parallel.RangeExchange(None, dist, K, ops=NumpyOps())
+        if chunk:
+            ex.CHUNK = chunk          # force several rounds per all-to-all (on the GPU a round is <= 256 MiB per peer)
         k, c = ex.exchange_and_merge(kt, ct, n)
         # every k-mer this rank now owns lies in its value range
         cuts = [0] + parallel.splitters(K, world) + [1 << (2 * K)]
@@ -133,9 +135,9 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_range_exchange_gloo(tmp_path, world):
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("world,chunk", [(2, None), (3, None), (2, 7001), (3, 1000)])
+def test_range_exchange_gloo(tmp_path, world, chunk):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), chunk), nprocs=world, join=True)
     parts = [np.load(str(tmp_path / ("r%d.npz" % r))) for r in range(world)]
     k = np.concatenate([p["k"] for p in parts])
     c = np.concatenate([p["c"] for p in parts])

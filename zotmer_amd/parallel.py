@@ -21,6 +21,8 @@ CPU tensors in the tests.
 result is range-partitioned and exchanged, and the received pieces are merged again; the global set
 is the concatenation of the ranks' pieces in rank order.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -107,14 +109,55 @@ class RangeExchange:
             self._rk = ops.empty(total + total // 16, torch.int64)
             self._rc = ops.empty(total + total // 16, counts_t.dtype)
         rk, rc = self._rk, self._rc
-        dist.all_to_all_single(rk[:total], keys_t[:n], recv, send)
-        dist.all_to_all_single(rc[:total], counts_t[:n], recv, send)
+        self._all_to_all_v(rk, keys_t, recv, send, pos)
+        self._all_to_all_v(rc, counts_t, recv, send, pos)
         ops.after_comm()
         segs, off = [], 0
         for m in recv:
             segs.append((off, m))
             off += m
         return rk, rc, segs
+
+    # elements per peer and round.  One all_to_all_single with a per-peer message above 1 GiB arrives with its second
+    # half wrong on this stack (RCCL 2.26.6 / torch 2.10, measured with a one-rank self exchange: 2^27 int64 fine,
+    # 2^27 + 1 corrupt), and config 2 on 8 GPUs sends 1.6 GB per peer -- so every message is cut to <= 256 MiB.
+    CHUNK = 1 << 25
+
+    def _all_to_all_v(self, out_t, in_t, recv, send, pos):
+        """out_t[roff[r] : roff[r] + recv[r]] <- rank r's in_t[pos[me] : pos[me + 1]], in rounds of at most CHUNK
+        elements per peer.  The slices of a round are not contiguous, so they go through two staging buffers."""
+        dist, W, CH = self.dist, self.world, self.CHUNK
+        roff = [0]
+        for m in recv:
+            roff.append(roff[-1] + m)
+        biggest = max([0] + list(send) + list(recv))
+        rounds = (biggest + CH - 1) // CH
+        if W > 1:
+            t = torch.tensor([rounds], dtype=torch.int64, device=in_t.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rounds = int(t.item())
+        if rounds <= 1:
+            dist.all_to_all_single(out_t[:roff[-1]], in_t[:pos[-1]], recv, send)
+            return
+        key = (in_t.dtype, in_t.device)
+        if getattr(self, "_stage", None) is None or self._stage[0] != key:
+            self._stage = (key, torch.empty(W * CH, dtype=in_t.dtype, device=in_t.device),
+                           torch.empty(W * CH, dtype=in_t.dtype, device=in_t.device))
+        _, s_buf, r_buf = self._stage
+        for j in range(rounds):
+            s_j = [min(max(m - j * CH, 0), CH) for m in send]
+            r_j = [min(max(m - j * CH, 0), CH) for m in recv]
+            o = 0
+            for r in range(W):
+                if s_j[r]:
+                    s_buf[o:o + s_j[r]].copy_(in_t[pos[r] + j * CH: pos[r] + j * CH + s_j[r]])
+                o += s_j[r]
+            dist.all_to_all_single(r_buf[:sum(r_j)], s_buf[:sum(s_j)], r_j, s_j)
+            o = 0
+            for r in range(W):
+                if r_j[r]:
+                    out_t[roff[r] + j * CH: roff[r] + j * CH + r_j[r]].copy_(r_buf[o:o + r_j[r]])
+                o += r_j[r]
 
     def exchange_and_merge(self, keys_t, counts_t, n):
         rk, rc, segs = self.exchange(keys_t, counts_t, n)
@@ -131,6 +174,9 @@ class RangeExchange:
         t = torch.tensor(halves(got) + halves(local_stream_sums), dtype=torch.int64, device=dev)
         self.dist.all_reduce(t)
         v = [int(x) for x in t.tolist()]
+        if os.environ.get("ZOT_DEBUG"):
+            import sys
+            sys.stderr.write("verify_global: got %r want %r reduced %r\n" % (got, local_stream_sums, v))
 
         def join(lo, hi):
             return [(l + (h << 32)) & 0xFFFFFFFFFFFFFFFF for l, h in zip(lo, hi)]
