@@ -109,6 +109,24 @@ def test_sort_keys_every_geometry(ctx, variant):
         ctx.tune(sort_variant=DEFAULT_SORT_VARIANT, pairs_variant=DEFAULT_SORT_VARIANT)
 
 
+@pytest.mark.parametrize("group", [1, 8, 32])
+def test_sort_keys_xcd_grouped_tile_order(ctx, group):
+    """zk_tune(ZK_TUNE_XCD_GROUP): runs of tiles handed to one XCD, work stealing at the tail -- off by default,
+    the result must not depend on it (including inputs smaller than one run and one-tile inputs)"""
+    try:
+        ctx.tune(xcd_group=group)
+        for n in (1, 5000, 8192 * 9 + 1, 8192 * 300 + 77):
+            rng = np.random.default_rng(n + group)
+            x = rng.integers(0, 1 << 50, size=n, dtype=np.uint64)
+            assert np.array_equal(ctx.sort_keys(ctx.upload(x), 50).to_host(), np.sort(x))
+        reads = synth.read_strings(9, 0, 3000, 150, genome=20000, sub_thr=synth.frac32(0.01), n_thr=synth.frac32(0.001))
+        want = zo.kmerize(25, reads)
+        k, c, _ = ctx.kmerize(ctx.upload_stream(stream_of(reads)), 25)
+        assert np.array_equal(k.to_host(), want["kmers"]) and np.array_equal(c.to_host(), want["counts"])
+    finally:
+        ctx.tune(xcd_group=0)
+
+
 def test_sort_keys_adversarial(ctx):
     n = 300001
     for x in (np.full(n, 0x23c48f123c48f, dtype=np.uint64),
