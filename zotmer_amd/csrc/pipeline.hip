@@ -30,6 +30,66 @@ __global__ void mirror_kernel(const u64* __restrict__ c, const u32* __restrict__
     }
 }
 
+// ---- the mirror list by groups (see kmerize_full) ---------------------------------------------------------
+constexpr int MIRROR_GROUP_BITS = 18;      // 9 bases: 2^18 groups, tables of 4 MB
+constexpr int MIRROR_GROUP_BASES = MIRROR_GROUP_BITS / 2;
+
+// start[g] = first index whose top MIRROR_GROUP_BITS bits are >= g (g = 2^18: n)
+__global__ void mirror_bounds_kernel(const u64* __restrict__ c, u64 n, int K, u64* __restrict__ start) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > (1u << MIRROR_GROUP_BITS)) return;
+    const u64 want = (u64)g << (2 * K - MIRROR_GROUP_BITS);
+    u64 lo = 0, hi = n;
+    if (g == (1u << MIRROR_GROUP_BITS)) lo = n;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (c[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    start[g] = lo;
+}
+
+// size_v[v] = size of the group whose mirrored keys end in v, i.e. group g = rc9(v)
+__global__ void mirror_sizes_kernel(const u64* __restrict__ start, u64* __restrict__ size_v) {
+    const u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= (1u << MIRROR_GROUP_BITS)) return;
+    const u32 g = (u32)revcomp(MIRROR_GROUP_BASES, (u64)v);
+    size_v[v] = start[g + 1] - start[g];
+}
+
+// exclusive scan of size_v in place (one workgroup of 1024 threads, 256 consecutive entries each)
+__global__ __launch_bounds__(1024) void mirror_scan_kernel(u64* __restrict__ size_v) {
+    constexpr int G = 1 << MIRROR_GROUP_BITS, PER = G / 1024;
+    __shared__ u64 wsum[16];
+    const int t = threadIdx.x;
+    u64 local = 0;
+#pragma unroll 16
+    for (int j = 0; j < PER; j++) local += size_v[t * PER + j];
+    const u64 inc = wave_incl_scan_u64(local);
+    if ((t & 63) == 63) wsum[t >> 6] = inc;
+    __syncthreads();
+    u64 off = 0;
+    for (int w = 0; w < (t >> 6); w++) off += wsum[w];
+    u64 run = off + inc - local;
+#pragma unroll 16
+    for (int j = 0; j < PER; j++) {
+        const u64 sz = size_v[t * PER + j];
+        size_v[t * PER + j] = run;
+        run += sz;
+    }
+}
+
+__global__ void mirror_copy_kernel(const u64* __restrict__ c, const u32* __restrict__ n, u64 m, int K, const u64* __restrict__ start,
+                                   const u64* __restrict__ dest, u64* __restrict__ r, u32* __restrict__ v) {
+    const int sh = 2 * K - MIRROR_GROUP_BITS;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (u64)gridDim.x * blockDim.x) {
+        const u64 x = c[i];
+        const u32 g = (u32)(x >> sh);
+        const u64 pos = dest[(u32)revcomp(MIRROR_GROUP_BASES, (u64)g)] + (i - start[g]);      // dest is indexed by v = rc9(g)
+        r[pos] = revcomp(K, x);
+        v[pos] = n[i];
+    }
+}
+
 __global__ void widen_kernel(const u32* __restrict__ in, u64* __restrict__ out, u64 m) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (u64)gridDim.x * blockDim.x) out[i] = in[i];
 }
@@ -85,10 +145,28 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     ZK_TRY(aux_require(c, 2 * a8 + 2 * a4, &aux));
     u64* rk = (u64*)aux; u64* rk2 = (u64*)(aux + a8);
     u32* rv = (u32*)(aux + 2 * a8); u32* rv2 = (u32*)(aux + 2 * a8 + a4);
-    // the mirrored pairs (rc c, n) are never written unsorted: the histogram and the first pass of their sort
-    // read (c, n) and reverse-complement on load
     u64* sk; u32* sv;
-    ZK_TRY(sort_pairs_mirrored(c, sorted, cnt, rk, rk2, rv, rv2, uc, K, &sk, &sv));
+    if (2 * K >= MIRROR_GROUP_BITS + 8 && uc >= (1ull << 16)) {
+        // The list (c, n) is sorted by c, so the k-mers that share their first 9 bases are contiguous -- and those are
+        // exactly the mirrored keys rc(c) that share their LAST 9 bases, i.e. their low 18 bits.  The first two passes of
+        // an LSD sort of the mirrored keys would only move these 2^18 groups around whole; one copy does it: group
+        // boundaries by binary search, group order = order of the reversed-complemented prefix, then only the bits
+        // above 18 are sorted.
+        u64 *start, *dest;
+        ZK_TRY(arena_alloc(c, sizeof(u64) * ((1u << MIRROR_GROUP_BITS) + 1), (void**)&start));
+        ZK_TRY(arena_alloc(c, sizeof(u64) * (1u << MIRROR_GROUP_BITS), (void**)&dest));
+        prof_begin(c, ZK_PROF_MIRROR, 24 * uc);
+        hipLaunchKernelGGL(mirror_bounds_kernel, dim3(((1u << MIRROR_GROUP_BITS) + 256) / 256), dim3(256), 0, c->stream, sorted, (u64)uc, K, start);
+        hipLaunchKernelGGL(mirror_sizes_kernel, dim3((1u << MIRROR_GROUP_BITS) / 256), dim3(256), 0, c->stream, start, dest);
+        hipLaunchKernelGGL(mirror_scan_kernel, dim3(1), dim3(1024), 0, c->stream, dest);
+        hipLaunchKernelGGL(mirror_copy_kernel, dim3(ew_grid(c, uc)), dim3(256), 0, c->stream, sorted, cnt, (u64)uc, K, start, dest, rk, rv);
+        prof_end(c);
+        ZK_HIP(c, hipGetLastError());
+        ZK_TRY(sort_pairs_upper(c, rk, rk2, rv, rv2, uc, 2 * K, MIRROR_GROUP_BITS, &sk, &sv));
+    } else {
+        // small inputs / short k-mers: the histogram and the first pass of the sort read (c, n) and reverse-complement on load
+        ZK_TRY(sort_pairs_mirrored(c, sorted, cnt, rk, rk2, rv, rv2, uc, K, &sk, &sv));
+    }
     return union_sum(c, sorted, cnt, uc, sk, sv, uc, out_k, out_c, 32, cap, n_out, nullptr);
 }
 
@@ -155,7 +233,7 @@ int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, dou
     const bool both = (flags & ZK_KMERIZE_BOTH) != 0;
     const uint64_t cap_keys = both ? 2 * n_bytes : n_bytes;   // one window per stream byte at most
     arena_reset(c);
-    const uint64_t slack = (1 << 20) + cap_keys / 16;
+    const uint64_t slack = (9 << 20) + cap_keys / 16;          // histograms, merge-path partitions, the mirror group tables (4 MB)
     ZK_TRY(arena_require(c, 16 * cap_keys + slack, 16 * cap_keys + slack));
     u64 *buf_a, *buf_b;
     ZK_TRY(arena_alloc(c, 8 * cap_keys, (void**)&buf_a));

@@ -1119,9 +1119,10 @@ struct Sorter {
 
     // mirror_K > 0: sort (rc(src_k[i]), src_v[i]) instead, without writing the mirrored keys first: the histogram and
     // the first pass apply rc on load; src_k / src_v are only read, keys/alt/vals/valt are the two work buffers.
+    // lo_bit > 0: only the bits [lo_bit, key_bits) are sorted (the input is already ordered by the bits below)
     static int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, u64** rk, u32** rv,
-                          const u64* src_k = nullptr, const u32* src_v = nullptr, int mirror_K = 0) {
-        PassPlan plan = make_plan(key_bits, C::RBITS);
+                          const u64* src_k = nullptr, const u32* src_v = nullptr, int mirror_K = 0, int lo_bit = 0) {
+        PassPlan plan = make_plan(key_bits - lo_bit, C::RBITS, lo_bit);
         u64* ghist;
         ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * C::RADIX, (void**)&ghist));
         SortArgs a = {};
@@ -1217,6 +1218,13 @@ int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n,
     *rk = keys; *rv = vals;
     if (n == 0) return ZK_OK;
     ZK_SORT_DISPATCH_V(c->pairs_variant, sort_pairs(c, keys, alt, vals, valt, n, key_bits, rk, rv));
+}
+
+// pairs already ordered by their low `lo_bit` bits: LSD passes over the bits above only
+int sort_pairs_upper(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, int lo_bit, u64** rk, u32** rv) {
+    *rk = keys; *rv = vals;
+    if (n == 0) return ZK_OK;
+    ZK_SORT_DISPATCH_V(c->pairs_variant, sort_pairs(c, keys, alt, vals, valt, n, key_bits, rk, rv, nullptr, nullptr, 0, lo_bit));
 }
 
 // (rc(src_k[i]), src_v[i]) sorted by key; keys/alt/vals/valt are work buffers, the source arrays are only read
