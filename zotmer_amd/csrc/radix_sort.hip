@@ -236,8 +236,10 @@ template <class C> struct NextTile<C, SRC_STREAM> {
     }
 };
 
-template <class C, int SRC>
-__global__ __launch_bounds__(C::BLOCK, (SRC == SRC_STREAM && C::BLOCK <= 512) ? 8 : 1) void hist_kernel(HistArgs h) {
+// PRE: stream source, one strand, 16 windows per thread made and counted on the fly (its own instantiation: the generic
+// path needs the sixteen keys in registers and would spill under the 8-waves-per-SIMD register cap)
+template <class C, int SRC, bool PRE = false>
+__global__ __launch_bounds__(C::BLOCK, PRE ? 8 : 1) void hist_kernel(HistArgs h) {
     __shared__ u32 bins[MAX_PASSES * C::RADIX];
     __shared__ TileImage<C::TILE> img;
     for (int i = threadIdx.x; i < MAX_PASSES * C::RADIX; i += C::BLOCK) bins[i] = 0;
@@ -245,8 +247,8 @@ __global__ __launch_bounds__(C::BLOCK, (SRC == SRC_STREAM && C::BLOCK <= 512) ? 
     __syncthreads();
     // stream source, one strand: the 16 bytes this thread stages for the NEXT tile are loaded while the current
     // tile is counted (two workgroups per CU do not hide a global round trip per tile on their own)
-    constexpr bool PREFETCH = (SRC == SRC_STREAM && C::ITEMS == 16);
-    const bool pre = PREFETCH && h.src.mode != ZK_KEYS_BOTH;
+    constexpr bool PREFETCH = PRE;
+    constexpr bool pre = PRE;
     NextTile<C, SRC_STREAM> nx;
     nx.q0 = nx.q1 = make_uint4(0, 0, 0, 0);
     if (pre && blockIdx.x < h.tiles) nx.issue(h.src, blockIdx.x, threadIdx.x, 0, 0);
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(C::BLOCK, (SRC == SRC_STREAM && C::BLOCK <= 512) ? 
                 live = 0;         // nothing left for the generic counting loop below
             }
         } else {
-            live = load_tile<C, SRC, false, SRC == SRC_STREAM>(h.src, tile, &img, key, val, pk);
+            if constexpr (!PRE) live = load_tile<C, SRC, false, SRC == SRC_STREAM>(h.src, tile, &img, key, val, pk);
         }
         a0 += pk & 0xffu; a1 += (pk >> 8) & 0xffu; a2 += (pk >> 16) & 0xffu; a3 += pk >> 24;
 #pragma unroll
@@ -1091,7 +1093,12 @@ struct Sorter {
         u32 grid = h.tiles < (u32)(c->num_cus * 8) ? h.tiles : (u32)(c->num_cus * 8);
         if (grid == 0) grid = 1;
         prof_begin(c, SRC == SRC_STREAM ? ZK_PROF_HIST_STREAM : ZK_PROF_HIST_ARRAY, SRC == SRC_STREAM ? src.n_bytes : 8 * src.n);
-        hipLaunchKernelGGL((hist_kernel<C, SRC>), dim3(grid), dim3(C::BLOCK), 0, c->stream, h);
+        if constexpr (SRC == SRC_STREAM && C::ITEMS == 16 && C::BLOCK <= 512) {
+            if (src.mode != ZK_KEYS_BOTH) hipLaunchKernelGGL((hist_kernel<C, SRC, true>), dim3(grid), dim3(C::BLOCK), 0, c->stream, h);
+            else hipLaunchKernelGGL((hist_kernel<C, SRC, false>), dim3(grid), dim3(C::BLOCK), 0, c->stream, h);
+        } else {
+            hipLaunchKernelGGL((hist_kernel<C, SRC, false>), dim3(grid), dim3(C::BLOCK), 0, c->stream, h);
+        }
         prof_end(c);
         ZK_HIP(c, hipGetLastError());
         hipLaunchKernelGGL(hist_scan_kernel, dim3(1), dim3(256), 0, c->stream, ghist, plan.passes, (int)C::RADIX, d_n);
