@@ -15,7 +15,7 @@ ctx.tune(sort_variant=variant)
 rng = np.random.default_rng(1)
 keys = ctx.upload(rng.integers(0, 1 << 50, size=n, dtype=np.uint64))
 tiles = (n + tile - 1) // tile
-dbg = ctx.empty(tiles * 9, np.uint64)
+dbg = ctx.empty(tiles * 17, np.uint64)
 ctx.sort_keys(keys, 50)           # warm
 keys = ctx.upload(rng.integers(0, 1 << 50, size=n, dtype=np.uint64))
 ctx._check(ctx.lib.zk_debug_buffer(ctx.h, dbg.ptr))
@@ -23,7 +23,8 @@ ctx.sort_keys(keys, 50)           # the stamps of the LAST pass remain
 ctx._check(ctx.lib.zk_debug_buffer(ctx.h, None))
 raw = dbg.to_host()
 s = raw[:tiles * 8].reshape(tiles, 8).astype(np.int64)
-ss = raw[tiles * 8:]
+ss = raw[tiles * 8:tiles * 9]
+per_wave = raw[tiles * 9:tiles * 17].reshape(tiles, 8).astype(np.int64)
 steps = (ss >> np.uint64(32)).astype(np.int64)[1:]
 spins = (ss & np.uint64(0xFFFFFFFF)).astype(np.int64)[1:]
 d = np.diff(s, axis=1)
@@ -31,9 +32,15 @@ pipe = variant == 3
 if pipe:
     ok = (s[:, 7] > 0) & (s[:, 0] > 0)
     s = s[ok]
-    seq = [("load wait", 0, 1), ("rank (wave 0)", 1, 2), ("barrier + scan + publish", 2, 4), ("parked (other tile's work)", 4, 3),
-           ("look-back (thread 0)", 3, 5), ("barrier after look-back", 5, 6), ("store", 6, 7)]
+    seq = [("B: load wait", 0, 1), ("B: rank (wave 0)", 1, 2), ("B: barrier + scan + publish", 2, 4),
+           ("(A's offsets, barrier, A's store, barrier) + park B", 4, 3), ("parked until offsets known", 3, 5),
+           ("A: barrier after offsets", 5, 6), ("A: store issue", 6, 7)]
     tot = s[:, 7] - s[:, 0]
+    pw = per_wave[ok]
+    good = (pw > 0).all(axis=1)
+    rel = pw[good] - pw[good].min(axis=1, keepdims=True)
+    print(json.dumps({"per_wave_offsets_known_minus_first_median": [float(np.median(rel[:, w])) for w in range(8)],
+                      "per_wave_is_last_fraction": [float((rel.argmax(axis=1) == w).mean()) for w in range(8)]}))
     print(json.dumps({"hops_mean": float(steps.mean()), "polls_mean": float(spins.mean()), "polls_p50_p90_p99": [float(np.percentile(spins, q)) for q in (50, 90, 99)],
                       "tiles": int(len(s)), "median_ticks_ticket_to_stored": float(np.median(tot)),
                       "phases_median_ticks": {nm: float(np.median(s[:, b] - s[:, a])) for nm, a, b in seq}}, indent=1))

@@ -927,7 +927,6 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
 
         if (vB) PSTAMP(tB, 4);
         if (have) {
-            PSTAMP(tileA, 3);
             // ---- tile A: offsets, then out of LDS ------------------------------------------------
 #pragma unroll
             for (int j = 0; j < DPT; j++) {
@@ -948,6 +947,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                 }
             }
             PSTAMP(tileA, 5);
+#ifdef ZK_STAMPS
+            if (a.dbg && lane == 0) a.dbg[9ull * tiles + 8ull * tileA + wave] = __builtin_amdgcn_s_memtime();   // per wave: offsets known
+#endif
         }
         __syncthreads();          // A's offsets and B's per-wave digit sums are visible
         if (vB) {
@@ -1001,6 +1003,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
         totalA = sm.total_live;
 #pragma unroll
         for (int j = 0; j < DPT; j++) { tcA[j] = tcB[j]; dexA[j] = dexB[j]; }
+        PSTAMP(tB, 3);          // B is parked
         have = true;
         tB = tC;
         vB = vC;
