@@ -281,6 +281,44 @@ def test_kmerize_short_sort_paths_agree(ctx, K):
         ctx.tune(short_sort=0, side_div=8)
 
 
+@pytest.mark.parametrize("case", ["u150", "u150_k13", "u100", "u40", "u255", "alt_149_151", "last_short", "n_at_separator", "one_read"])
+def test_kmerize_record_aligned_tiles_and_fallbacks(ctx, case):
+    """Pass 0 lays its tiles along the records when every record has the same length (checked on the device); any other
+    stream takes tiles of positions.  Same answer either way, also for streams built to look uniform but are not."""
+    rng = np.random.default_rng(len(case))
+
+    def rnd(n, p_n=0.002):
+        a = rng.choice(list("ACGT"), size=n)
+        a[rng.random(n) < p_n] = "N"
+        return "".join(a)
+    K = 25
+    if case == "u150":
+        reads = [rnd(150) for _ in range(1333)]                    # not a multiple of the 64 records of a tile
+    elif case == "u150_k13":
+        K, reads = 13, [rnd(150) for _ in range(700)]              # 9 chunks cover 144 > 138 windows: the tail is masked
+    elif case == "u100":
+        reads = [rnd(100) for _ in range(2000)]                    # 5 chunks per record, 96 records per tile
+    elif case == "u40":
+        reads = [rnd(40) for _ in range(3000)]                     # one chunk per record: too many bytes per tile, falls back
+    elif case == "u255":
+        reads = [rnd(255) for _ in range(600)]
+    elif case == "alt_149_151":
+        reads = [rnd(149 if i % 2 == 0 else 151) for i in range(1500)]      # same total per pair, never uniform
+    elif case == "last_short":
+        reads = [rnd(150) for _ in range(900)] + [rnd(77)]
+    elif case == "n_at_separator":
+        reads = [rnd(150) for _ in range(500)]
+        reads[3] = reads[3][:100] + "N" + reads[3][101:]           # fine: an N inside a record
+        reads[7] = rnd(301)                                          # a long record whose middle byte sits on the separator grid
+        reads[7] = reads[7][:150] + "N" + reads[7][151:]
+    else:
+        reads = [rnd(150)]
+    want = zo.kmerize(K, reads)
+    k, c, st = ctx.kmerize(ctx.upload_stream(stream_of(reads)), K)
+    assert np.array_equal(k.to_host(), want["kmers"]) and np.array_equal(c.to_host(), want["counts"])
+    assert list(st.acgt) == want["acgt"]
+
+
 @pytest.mark.parametrize("K", [4, 24, 32])
 def test_kmerize_even_K_palindromes_vs_oracle(ctx, K):
     # even K: x == rc(x) exists; the mirrored path must count such a window twice, like two emissions

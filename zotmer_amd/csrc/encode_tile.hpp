@@ -128,6 +128,35 @@ __device__ __forceinline__ u32 windows16(const TileImage<T>& img, int j, int K, 
     return ok;
 }
 
+// The 16 windows that start at an ARBITRARY tile position p0 (record-aligned tiles): the same algebra with the
+// in-chunk offset s = p0 & 15 a per-lane value, so the shifts are register shifts instead of constants.
+// s + 15 + K <= 15 + 15 + 32 = 62 bases: still inside the 64 bases of four words.
+template <int T>
+__device__ __forceinline__ u32 windows16_at(const TileImage<T>& img, int p0, int K, u64 (&x)[16], u64 (&xb)[16]) {
+    const int j = p0 >> 4, s = p0 & 15;
+    const u64 a = ((u64)img.codes[j] << 32) | img.codes[j + 1];
+    const u64 b = ((u64)img.codes[j + 2] << 32) | img.codes[j + 3];
+    const u64 rhi = rev_pairs(~b), rlo = rev_pairs(~a);
+    const u64 mask = ~0ull >> (64 - 2 * K);
+    u64 v = ((u64)img.valid[j] << 48) | ((u64)img.valid[j + 1] << 32) | ((u64)img.valid[j + 2] << 16) | (u64)img.valid[j + 3];
+    int have = 1;
+    while (2 * have <= K) { v &= v << have; have *= 2; }
+    v &= v << (K - have);
+    v <<= s;                                        // bit 63-i = window s+i
+    u32 ok = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int sh = 128 - 2 * (s + i) - 2 * K;   // 4 .. 126, per lane
+        const u64 hi_part = a >> ((sh - 64) & 63);
+        const u64 lo_part = (a << ((64 - sh) & 63)) | (b >> (sh & 63));
+        x[i] = ((sh >= 64) ? hi_part : lo_part) & mask;
+        const int r = 2 * (s + i);                  // 0 .. 60
+        xb[i] = (r ? ((rlo >> r) | (rhi << ((64 - r) & 63))) : rlo) & mask;
+        ok |= (u32)((v >> (63 - i)) & 1ull) << i;
+    }
+    return ok;
+}
+
 // The same, one window at a time, for a consumer that does not keep the 16 keys (the digit histogram):
 // eight registers of state instead of sixty-four of results.
 template <int T>

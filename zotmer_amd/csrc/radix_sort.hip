@@ -82,6 +82,10 @@ struct SortArgs {
     u64 n_bytes;
     int K;
     int mode;
+    // stream source, record-aligned tiles (pipeline pass 0; 0 = tiles of TILE stream positions): every record is `rec`
+    // bytes (rec - 1 bases + the separator); a tile takes `rpt` records, a thread one of the `cpr` 16-window chunks of a
+    // record, which has `wpr` windows.  Verified by the histogram kernel before it is used (see sort_stream).
+    u32 rec, rpt, cpr, wpr;
     // outputs
     u64* kout;
     u32* vout;
@@ -199,7 +203,21 @@ struct HistArgs {
     u64* ghist;          // [MAX_PASSES][RADIX], zeroed by the host
     u64* acgt;           // [4] or null
     u32 tiles;
+    u64* rec_info;       // PRE only: [0] = position of the stream's first newline (read), [1] += newline bytes,
+                         // [2] += 16-byte chunks whose newlines are not exactly the record separators
 };
+
+// position of the first '\n' in the head of the stream (~0 if there is none): the record length, if records are uniform
+__global__ void first_newline_kernel(const u8* __restrict__ stream, u64 n_bytes, u64* out) {
+    __shared__ u32 best;
+    if (threadIdx.x == 0) best = 0xffffffffu;
+    __syncthreads();
+    const u64 lim = n_bytes < 65536 ? n_bytes : 65536;
+    for (u64 i = threadIdx.x; i < lim; i += blockDim.x)
+        if (stream[i] == '\n') atomicMin(&best, (u32)i);
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (best == 0xffffffffu) ? ~0ull : (u64)best;
+}
 
 // what a workgroup of the pipeline has in flight for its next tile
 template <class C, int SRC> struct NextTile;
@@ -229,10 +247,11 @@ template <class C> struct NextTile<C, SRC_ARRAY> {
 template <class C> struct NextTile<C, SRC_STREAM> {
     uint4 q0, q1;        // this thread's 16-byte chunk(s) of the tile's stream bytes
     __device__ __forceinline__ void issue(const SortArgs& a, u32 t, int tid, int wave, int lane) {
-        const u64 t0 = (u64)t * C::TILE;
-        q0 = load_chunk16(a.stream, a.n_bytes, t0 + 16ull * tid);
-        q1 = make_uint4(0, 0, 0, 0);
-        if (tid + C::BLOCK < TileImage<C::TILE>::NCH) q1 = load_chunk16(a.stream, a.n_bytes, t0 + 16ull * (tid + C::BLOCK));
+        const u64 t0 = a.rec ? (u64)t * a.rpt * a.rec : (u64)t * C::TILE;
+        const u32 nch = a.rec ? (a.rpt * a.rec) / 16 + 3 : (u32)TileImage<C::TILE>::NCH;
+        q0 = q1 = make_uint4(0, 0, 0, 0);
+        if ((u32)tid < nch) q0 = load_chunk16(a.stream, a.n_bytes, t0 + 16ull * tid);
+        if ((u32)tid + C::BLOCK < nch) q1 = load_chunk16(a.stream, a.n_bytes, t0 + 16ull * (tid + C::BLOCK));
     }
 };
 
@@ -252,6 +271,18 @@ __global__ __launch_bounds__(C::BLOCK, PRE ? 8 : 1) void hist_kernel(HistArgs h)
     NextTile<C, SRC_STREAM> nx;
     nx.q0 = nx.q1 = make_uint4(0, 0, 0, 0);
     if (pre && blockIdx.x < h.tiles) nx.issue(h.src, blockIdx.x, threadIdx.x, 0, 0);
+    // Are the records uniform (every rec-th byte a newline and no other newline)?  rec comes from the position of the
+    // stream's first newline; this kernel reads every byte anyway, so it checks: newline bytes are counted, and every
+    // 16-byte chunk whose newlines are not exactly the expected separator is counted as bad.
+    u32 rec = 0, m = 0, step_m = 0, nl_count = 0, bad_count = 0;
+    if (PRE && h.rec_info) {
+        const u64 first_nl = h.rec_info[0];
+        if (first_nl < 0x7fffffffull) {
+            rec = (u32)first_nl + 1u;
+            m = (u32)(((u64)blockIdx.x * C::TILE + 16ull * threadIdx.x) % rec);
+            step_m = (u32)(((u64)gridDim.x * C::TILE) % rec);
+        }
+    }
     for (u32 tile = blockIdx.x; tile < h.tiles; tile += gridDim.x) {
         u64 key[C::ITEMS];
         u32 val[C::ITEMS];
@@ -259,6 +290,24 @@ __global__ __launch_bounds__(C::BLOCK, PRE ? 8 : 1) void hist_kernel(HistArgs h)
         u32 live = 0;
         if (pre) {
             if constexpr (PREFETCH) {
+                if (rec) {
+                    const u32 w4[4] = {nx.q0.x, nx.q0.y, nx.q0.z, nx.q0.w};
+                    const int sep = (int)(rec - 1u) - (int)m;          // where this chunk's separator is, if < 16
+                    const u64 off = (u64)tile * C::TILE + 16ull * threadIdx.x;
+                    const bool expect = sep >= 0 && sep < 16 && off + (u64)sep < h.src.n_bytes;
+                    bool bad = false;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const u32 x = w4[q] ^ 0x0a0a0a0au;              // zero byte <=> newline
+                        const u32 t = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);   // 0x80 in every zero byte, exact
+                        nl_count += (u32)__popc(t);
+                        const u32 want = (expect && (sep >> 2) == q) ? (0x80u << (8 * (sep & 3))) : 0u;
+                        bad |= (t != want);
+                    }
+                    bad_count += bad ? 1u : 0u;
+                    m += step_m;
+                    if (m >= rec) m -= rec;
+                }
                 u32 cc, vv;
                 encode_words16(nx.q0, cc, vv);
                 img.codes[threadIdx.x] = cc; img.valid[threadIdx.x] = vv;
@@ -326,6 +375,13 @@ __global__ __launch_bounds__(C::BLOCK, PRE ? 8 : 1) void hist_kernel(HistArgs h)
     for (int i = threadIdx.x; i < h.plan.passes * C::RADIX; i += C::BLOCK) {
         u32 v = bins[i];
         if (v) atomicAdd(&h.ghist[i], (u64)v);
+    }
+    if (PRE && rec) {
+        nl_count = wave_sum_u32(nl_count); bad_count = wave_sum_u32(bad_count);
+        if ((threadIdx.x & 63) == 0) {
+            if (nl_count) atomicAdd(&h.rec_info[1], (u64)nl_count);
+            if (bad_count) atomicAdd(&h.rec_info[2], (u64)bad_count);
+        }
     }
     if (h.acgt) {
         a0 = wave_sum_u32(a0); a1 = wave_sum_u32(a1); a2 = wave_sum_u32(a2); a3 = wave_sum_u32(a3);
@@ -697,10 +753,13 @@ __device__ __forceinline__ u32 steal_tile(const SortArgs& a, u32 x, u32 tiles) {
 template <class C>
 struct PipeSmem {
     static constexpr bool IMG_FITS = sizeof(TileImage<C::TILE>) <= sizeof(u16) * C::NW * C::RADIX;
+    // the image takes the whole counter area: room for record-aligned tiles, whose byte span exceeds TILE
+    static constexpr int IMG_WORDS = (int)(sizeof(u16) * C::NW * C::RADIX / 8);     // per array (codes, valid)
+    static constexpr int IMG_T = IMG_FITS ? (IMG_WORDS - 3) * 16 : 16;
     u64 exch[C::TILE];              // tile A, grouped by digit, until its offsets are known
     union {
         u16 cnt[C::NW][C::RADIX];
-        TileImage<PipeSmem::IMG_FITS ? C::TILE : 16> img;     // stream source: the 2-bit image of tile B, dead before cnt is zeroed
+        TileImage<PipeSmem::IMG_T> img;     // stream source: the 2-bit image of tile B, dead before cnt is zeroed
     };
     u32 digit_off[C::RADIX];
     u64 gbase[C::RADIX];
@@ -715,8 +774,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
     static_assert(C::ROUNDS == 1, "the pipeline parks a whole tile in LDS");
     constexpr int NS = RADIX / 64;          // scanner workgroups: 64 digits each
     __shared__ PipeSmem<C> sm;
-    static_assert(SRC == SRC_ARRAY || sizeof(TileImage<C::TILE>) <= sizeof(u16) * C::NW * C::RADIX, "the tile image lives in the counter area");
-    static_assert(SRC == SRC_ARRAY || (ITEMS == 16 && TileImage<TILE>::NCH <= 2 * BLOCK), "stream source: 16 consecutive windows per thread");
+    static_assert(SRC == SRC_ARRAY || PipeSmem<C>::IMG_FITS, "the tile image lives in the counter area");
+    static_assert(SRC == SRC_ARRAY || (ITEMS == 16 && PipeSmem<C>::IMG_WORDS <= 2 * BLOCK), "stream source: 16 consecutive windows per thread");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 dmask = (1u << a.bits) - 1u;
     u16* mycnt = sm.cnt[wave];
@@ -841,16 +900,31 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                 live = nx.live;
             } else {
                 __syncthreads();      // the waves that parked the previous tile are done with the counters (same LDS)
+                const u32 nch = a.rec ? (a.rpt * a.rec) / 16 + 3 : (u32)TileImage<TILE>::NCH;
                 u32 cc, vv;
-                encode_words16(nx.q0, cc, vv);
-                sm.img.codes[tid] = cc; sm.img.valid[tid] = vv;
-                if (tid + BLOCK < TileImage<TILE>::NCH) {
+                if ((u32)tid < nch) {
+                    encode_words16(nx.q0, cc, vv);
+                    sm.img.codes[tid] = cc; sm.img.valid[tid] = vv;
+                }
+                if ((u32)tid + BLOCK < nch) {
                     encode_words16(nx.q1, cc, vv);
                     sm.img.codes[tid + BLOCK] = cc; sm.img.valid[tid + BLOCK] = vv;
                 }
                 __syncthreads();
                 u64 xs[16], xr[16];
-                live = windows16(sm.img, tid, a.K, xs, xr);
+                // One code path for both tile shapes (two would double the registers): the thread's first window is at
+                // tile position p0 -- 16 * tid for tiles of TILE positions; for record-aligned tiles thread = (record r
+                // of the tile, chunk j of its windows), so that no slot is spent on the K windows per record that
+                // run into the separator.
+                u32 p0 = 16u * (u32)tid, lim = 0xffffu;
+                if (a.rec) {
+                    const u32 r = (u32)tid / a.cpr, j = (u32)tid - r * a.cpr;
+                    p0 = r * a.rec + 16u * j;
+                    const int left = (int)a.wpr - 16 * (int)j;              // windows of the record from this chunk on
+                    lim = (r < a.rpt) ? ((left >= 16) ? 0xffffu : ((1u << (left > 0 ? left : 0)) - 1u)) : 0u;
+                    if (r >= a.rpt) p0 = 0;
+                }
+                live = windows16_at(sm.img, (int)p0, a.K, xs, xr) & lim;
 #pragma unroll
                 for (int i = 0; i < ITEMS; i++) {
                     const u64 x = xs[i & 15], xb = xr[i & 15];
@@ -1023,6 +1097,7 @@ template <class C>
 struct Sorter {
     static u32 tiles_for(const SortArgs& a, int src) {
         if (src == SRC_ARRAY) return (u32)div_up(a.n, C::TILE);
+        if (a.rec) return (u32)div_up(a.n_bytes / a.rec, a.rpt);           // record-aligned tiles (pipeline pass 0 only)
         const u64 pos = (a.mode == ZK_KEYS_BOTH) ? C::TILE / 2 : C::TILE;
         return (u32)div_up(a.n_bytes, pos);
     }
@@ -1091,7 +1166,13 @@ struct Sorter {
         h.ghist = ghist;
         h.acgt = acgt;
         h.tiles = tiles_for(src, SRC);
+        h.rec_info = nullptr;
         ZK_HIP(c, hipMemsetAsync(ghist, 0, sizeof(u64) * MAX_PASSES * C::RADIX, c->stream));
+        if (SRC == SRC_STREAM && src.n_bytes) {
+            h.rec_info = c->d_scalars + 20;
+            ZK_HIP(c, hipMemsetAsync(h.rec_info, 0, 3 * sizeof(u64), c->stream));
+            hipLaunchKernelGGL(first_newline_kernel, dim3(1), dim3(256), 0, c->stream, src.stream, (u64)src.n_bytes, h.rec_info);
+        }
         if (acgt) ZK_HIP(c, hipMemsetAsync(acgt, 0, sizeof(u64) * 4, c->stream));
         u32 grid = h.tiles < (u32)(c->num_cus * 8) ? h.tiles : (u32)(c->num_cus * 8);
         if (grid == 0) grid = 1;
@@ -1166,7 +1247,7 @@ struct Sorter {
         u64* d_n = c->d_scalars + 8;
         ZK_TRY(launch_hist<SRC_STREAM>(c, a, plan, ghist, d_acgt, d_n));
         // the number of live keys decides the grids of the array passes: one small readback
-        ZK_HIP(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(u64) * 16, hipMemcpyDeviceToHost, c->stream));
+        ZK_HIP(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(u64) * 24, hipMemcpyDeviceToHost, c->stream));
         ZK_HIP(c, hipStreamSynchronize(c->stream));
         const uint64_t n = c->h_scalars[8];
         if (acgt) for (int b = 0; b < 4; b++) acgt[b] = c->h_scalars[b];
@@ -1175,13 +1256,30 @@ struct Sorter {
         if (n == 0) return ZK_OK;
         a.kout = buf_a; a.shift = plan.shift[0]; a.bits = plan.bits[0]; a.ghist = ghist;
         a.n = n;
-        if constexpr (C::PIPE && C::ITEMS == 16 && PipeSmem<C>::IMG_FITS) {
+        if constexpr (C::PIPE && C::ITEMS == 16 && PipeSmem<C>::IMG_FITS && C::BLOCK <= 512) {
+            // Uniform records (checked by the histogram kernel: the only newlines are one every `rec` bytes): tiles follow
+            // the records, so that no key slot is spent on the windows that run into a separator (17 % of the
+            // positions for 150-base reads and K = 25).  Any other stream: tiles of TILE positions.
+            const uint64_t first_nl = c->h_scalars[20], nl = c->h_scalars[21], bad = c->h_scalars[22];
+            if (src.mode != ZK_KEYS_BOTH && first_nl < 0x7fffffffull) {
+                const uint64_t rec = first_nl + 1;
+                const int64_t W = (int64_t)first_nl - src.K + 1;
+                if (rec >= 16 && W >= 1 && src.n_bytes % rec == 0 && bad == 0 && nl == src.n_bytes / rec) {
+                    const uint32_t cpr = (uint32_t)((W + 15) / 16);
+                    const uint32_t rpt = (C::BLOCK / cpr) / 16 * 16;
+                    if (rpt >= 16 && (uint64_t)rpt * rec / 16 + 3 <= (uint64_t)PipeSmem<C>::IMG_WORDS &&
+                        (double)rpt * (double)W > 1.02 * (double)C::TILE * (double)W / (double)rec) {
+                        a.rec = (u32)rec; a.rpt = rpt; a.cpr = cpr; a.wpr = (u32)W;
+                    }
+                }
+            }
             if (src.mode != ZK_KEYS_BOTH) ZK_TRY(launch_pipe<SRC_STREAM>(c, a));
             else ZK_TRY((launch_pass<SRC_STREAM, false>(c, a)));
         } else {
             ZK_TRY((launch_pass<SRC_STREAM, false>(c, a)));
         }
         u64* in = buf_a; u64* out = buf_b;
+        a.rec = 0;
         for (int p = 1; p < plan.passes; p++) {
             a.kin = in; a.kout = out; a.shift = plan.shift[p]; a.bits = plan.bits[p];
             a.ghist = ghist + p * C::RADIX;
