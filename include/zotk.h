@@ -65,6 +65,7 @@ int zk_copy(zk_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes);   /* d
 #define ZK_TUNE_SHORT_SORT 3     /* zk_kmerize: 1 = sort only the top ~log2(n)+3 bits, finish in the mirror stage (default 0) */
 #define ZK_TUNE_XCD_GROUP 5    /* radix-sort pipeline: runs of this many consecutive tiles go to one XCD (0 = off, the default; <= 32) */
 #define ZK_TUNE_SIDE_DIV 4       /* ... side-list capacity = n / value (default 8); overflow falls back to the full sort */
+#define ZK_TUNE_COMM_CHUNK 6     /* zk_all_to_all_v: bytes per message and round (0 = 256 MiB, the default) */
 int zk_tune(zk_ctx* ctx, int what, int value);
 
 /* Per-launch timing with HIP events recorded on the ctx's own stream (what bench.py's roofline
@@ -188,6 +189,35 @@ int zk_project(zk_ctx* ctx, const uint64_t* d_ref, uint64_t n_ref, const uint64_
 int zk_sample(zk_ctx* ctx, const uint64_t* d_kmers, const uint64_t* d_counts, uint64_t n, uint64_t seed, double p,
               uint64_t* d_ok, uint64_t* d_oc, uint64_t cap, uint64_t* n_out);
 
+/* ---- multi-GPU: partitioning and the RCCL seam ------------------------------------- */
+
+/* Hash-range owner: owner(x) = floor(murmer(x, seed) * world / 2^64) (basics.murmer, library/basics.py:191-229).
+ * Splits a sorted (k-mer, count) table into `world` pieces, each still sorted (a stable partition); piece o is
+ * d_ok[offsets[o] .. offsets[o+1]).  d_counts / d_oc may be NULL (keys only); offsets is a HOST array of world + 1
+ * entries; world <= 32.  The value-range owner needs no kernel: a sorted table is already partitioned, the cut
+ * points come from zk_lower_bound. */
+int zk_hash_partition(zk_ctx* ctx, const uint64_t* d_kmers, const void* d_counts, int count_bits, uint64_t n, int world, uint64_t seed,
+                      uint64_t* d_ok, void* d_oc, uint64_t* offsets);
+
+/* One RCCL communicator per context, one process per GPU.  The reference is single-process (no counterpart);
+ * these are the entry points a host that is not PyTorch binds to drive the 8-GPU path.  Rank 0 makes the id and
+ * the host carries its 128 bytes to the other ranks (file, MPI, torch.distributed store ...). */
+#define ZK_COMM_ID_BYTES 128
+#define ZK_REDUCE_SUM 0          /* modulo 2^64 */
+#define ZK_REDUCE_MAX 1
+int zk_comm_unique_id(uint8_t id[ZK_COMM_ID_BYTES]);
+int zk_comm_init(zk_ctx* ctx, int world, int rank, const uint8_t id[ZK_COMM_ID_BYTES]);
+int zk_comm_destroy(zk_ctx* ctx);
+int zk_comm_info(zk_ctx* ctx, int* world, int* rank);          /* 1, 0 without a communicator */
+/* The exchange step: elements [send_off[r], send_off[r] + send_cnt[r]) of d_send go to rank r, which receives them
+ * at recv_off[me] of its d_recv (recv_cnt[r] on this rank must equal send_cnt[me] on rank r); offsets and counts are
+ * HOST arrays of `world` entries in units of elem_bytes.  Grouped ncclSend / ncclRecv, one hop per peer on the xGMI
+ * mesh, straight between the callers' arrays, <= 256 MiB per message and round; asynchronous on the ctx's stream. */
+int zk_all_to_all_v(zk_ctx* ctx, const void* d_send, const uint64_t* send_off, const uint64_t* send_cnt, void* d_recv,
+                    const uint64_t* recv_off, const uint64_t* recv_cnt, int elem_bytes);
+/* in-place all-reduce of n HOST values (dist's (a, b, c), checksums, the splitter histogram); synchronises */
+int zk_allreduce_u64(zk_ctx* ctx, uint64_t* vals, uint64_t n, int op);
+
 /* ---- K10: trim ---------------------------------------------------------------------------------- */
 
 /* trim.trim (commands/trim.py:54-62): keep (x, f) iff f >= lo and (hi == 0 or f <= hi). */
@@ -238,6 +268,17 @@ int zk_synth_reads(zk_ctx* ctx, uint64_t seed, uint64_t first, uint64_t count, i
 /* sum of x and of murmer(x, 0) * count over a counted set, mod 2^64: order-free checksums used by
  * the full-size parity tests.  d_counts may be NULL (every count 1). */
 int zk_checksum(zk_ctx* ctx, const uint64_t* d_kmers, const uint32_t* d_counts, uint64_t n, uint64_t sums[3]);
+
+/* zk_checksum over 32- or 64-bit counts (`zot merge` works on 64-bit counts) */
+int zk_checksum_counts(zk_ctx* ctx, const uint64_t* d_kmers, const void* d_counts, int count_bits, uint64_t n, uint64_t sums[3]);
+
+/* Synthetic k-mer sets (BASELINE configs 3 and 4; zotmer_amd/synth.py set_keys / set_counts is the specification).
+ * d_out[i] = rnd(seed, 7, (mul * (first + i) + add) % mod) & (2^key_bits - 1): element first + i of an affine walk through
+ * a pool of `mod` random keys (unsorted; sort and dedupe with zk_sort_count).  zk_synth_counts: geometric counts
+ * (mean 8) as a function of (seed, key). */
+int zk_synth_keys(zk_ctx* ctx, uint64_t seed, uint64_t first, uint64_t count, int key_bits, uint64_t mul, uint64_t add, uint64_t mod,
+                  uint64_t* d_out);
+int zk_synth_counts(zk_ctx* ctx, uint64_t seed, const uint64_t* d_keys, uint64_t n, uint64_t* d_counts);
 
 /* the same three sums over every k-mer instance (x and rc(x) of each valid window) of a base
  * stream, computed straight from the stream without sorting anything; sums[3..6] = acgt[x & 3]

@@ -116,7 +116,7 @@ static u32 grid_for(zk_ctx* c, u64 n, u64 per_block) {
 
 using namespace zk;
 
-#define ZK_ARGS(c, cond) do { if (!(c)) return ZK_EINVAL; if (!(cond)) return zk::fail((c), ZK_EINVAL, "bad argument: %s", #cond); } while (0)
+#define ZK_ARGS(c, cond) do { if (!(c)) return ZK_EINVAL; zk::enter(c); if (!(cond)) return zk::fail((c), ZK_EINVAL, "bad argument: %s", #cond); } while (0)
 
 extern "C" {
 

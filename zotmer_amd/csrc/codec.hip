@@ -145,6 +145,18 @@ __global__ __launch_bounds__(CD_BLOCK) void scan64_kernel(u64* __restrict__ v, u
         if (base + i < n) v[base + i] = x[i] + add;
 }
 
+// in-place 64-bit inclusive prefix sum of a device array (asynchronous on the stream)
+int scan64_inclusive(zk_ctx* c, u64* d_v, uint64_t n) {
+    if (n == 0) return ZK_OK;
+    CdState s2;
+    s2.tiles = (u32)div_up(n, SCAN_TILE);
+    ZK_TRY(lookback_begin(c, 2ull * s2.tiles, s2.tiles, &s2.epoch, &s2.ticket_base));
+    s2.status = c->status; s2.ticket = c->d_ticket; s2.err = c->d_err; s2.d_total = c->d_scalars + 9;
+    hipLaunchKernelGGL(scan64_kernel, dim3(s2.tiles), dim3(CD_BLOCK), 0, c->stream, d_v, (u64)n, c->status, c->status + s2.tiles, s2);
+    ZK_HIP(c, hipGetLastError());
+    return ZK_OK;
+}
+
 int codec_decode(zk_ctx* c, const u64* d_words, uint64_t nw, int delta, u64* d_out, uint64_t cap, uint64_t* n_out) {
     *n_out = 0;
     if (nw == 0) return ZK_OK;
@@ -160,12 +172,7 @@ int codec_decode(zk_ctx* c, const u64* d_words, uint64_t nw, int delta, u64* d_o
     *n_out = n;                      // also when the output was too small: lets the caller size it
     ZK_TRY(check_device_error(c));
     if (delta && n) {
-        CdState s2;
-        s2.tiles = (u32)div_up(n, SCAN_TILE);
-        ZK_TRY(lookback_begin(c, 2ull * s2.tiles, s2.tiles, &s2.epoch, &s2.ticket_base));
-        s2.status = c->status; s2.ticket = c->d_ticket; s2.err = c->d_err; s2.d_total = c->d_scalars + 9;
-        hipLaunchKernelGGL(scan64_kernel, dim3(s2.tiles), dim3(CD_BLOCK), 0, c->stream, d_out, (u64)n, c->status, c->status + s2.tiles, s2);
-        ZK_HIP(c, hipGetLastError());
+        ZK_TRY(scan64_inclusive(c, d_out, n));
         ZK_HIP(c, hipStreamSynchronize(c->stream));
         ZK_TRY(check_device_error(c));
     }

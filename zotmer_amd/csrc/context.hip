@@ -221,6 +221,7 @@ void zk_destroy(zk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)zk_comm_destroy(c);
     for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (c->arena) (void)hipFree(c->arena);
     if (c->aux) (void)hipFree(c->aux);
@@ -239,6 +240,7 @@ const char* zk_last_error(zk_ctx* c) { return c ? c->last_error.c_str() : g_crea
 
 int zk_set_stream(zk_ctx* c, void* hip_stream) {
     if (!c) return ZK_EINVAL;
+    enter(c);
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     if (c->own_stream) { (void)hipStreamDestroy(c->stream); c->own_stream = false; }
     if (hip_stream) c->stream = (hipStream_t)hip_stream;
@@ -253,12 +255,14 @@ void* zk_get_stream(zk_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int zk_sync(zk_ctx* c) {
     if (!c) return ZK_EINVAL;
+    enter(c);
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     return ZK_OK;
 }
 
 int zk_reserve(zk_ctx* c, uint64_t workspace_bytes) {
     if (!c) return ZK_EINVAL;
+    enter(c);
     if (workspace_bytes <= c->arena_size) return ZK_OK;
     arena_reset(c);
     void* p;
@@ -269,6 +273,7 @@ int zk_reserve(zk_ctx* c, uint64_t workspace_bytes) {
 
 int zk_mem_info(zk_ctx* c, uint64_t* free_bytes, uint64_t* total_bytes) {
     if (!c) return ZK_EINVAL;
+    enter(c);
     size_t f = 0, t = 0;
     ZK_HIP(c, hipMemGetInfo(&f, &t));
     if (free_bytes) *free_bytes = f;
@@ -278,10 +283,12 @@ int zk_mem_info(zk_ctx* c, uint64_t* free_bytes, uint64_t* total_bytes) {
 
 int zk_tune(zk_ctx* c, int what, int value) {
     if (!c) return ZK_EINVAL;
+    enter(c);
     if (what == ZK_TUNE_SORT_VARIANT) { c->sort_variant = value; return ZK_OK; }
     if (what == ZK_TUNE_PAIRS_VARIANT) { c->pairs_variant = value; return ZK_OK; }
     if (what == ZK_TUNE_SHORT_SORT) { c->short_sort = value; return ZK_OK; }
     if (what == ZK_TUNE_SIDE_DIV) { c->side_div = value; return ZK_OK; }
+    if (what == ZK_TUNE_COMM_CHUNK) { c->comm_chunk_bytes = value > 0 ? (uint64_t)value : 0; return ZK_OK; }
     if (what == ZK_TUNE_XCD_GROUP) {
         if (value < 0 || value > 32 || (value & (value - 1))) return fail(c, ZK_EINVAL, "xcd group must be 0 or a power of two <= 32");
         c->xcd_group = value;
@@ -293,12 +300,14 @@ int zk_tune(zk_ctx* c, int what, int value) {
 // diagnostic builds only (-DZK_STAMPS): where pass_kernel writes its per-tile time stamps
 int zk_debug_buffer(zk_ctx* c, void* d_buf) {
     if (!c) return ZK_EINVAL;
+    enter(c);
     c->dbg = (u64*)d_buf;
     return ZK_OK;
 }
 
 int zk_profile(zk_ctx* c, int enable) {
     if (!c) return ZK_EINVAL;
+    enter(c);
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     c->prof.clear();
@@ -308,6 +317,7 @@ int zk_profile(zk_ctx* c, int enable) {
 
 int zk_profile_read(zk_ctx* c, int tag, uint64_t* launches, double* total_ms, uint64_t* total_bytes) {
     if (!c) return ZK_EINVAL;
+    enter(c);
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     uint64_t n = 0, bytes = 0;
     double ms = 0;
@@ -325,6 +335,7 @@ int zk_profile_read(zk_ctx* c, int tag, uint64_t* launches, double* total_ms, ui
 
 int zk_alloc(zk_ctx* c, uint64_t bytes, void** dptr) {
     if (!c || !dptr) return ZK_EINVAL;
+    enter(c);
     *dptr = nullptr;
     if (bytes == 0) bytes = 256;
     hipError_t e = hipMalloc(dptr, bytes);
@@ -334,12 +345,14 @@ int zk_alloc(zk_ctx* c, uint64_t bytes, void** dptr) {
 
 int zk_free(zk_ctx* c, void* dptr) {
     if (!c) return ZK_EINVAL;
+    enter(c);
     if (dptr) { ZK_HIP(c, hipStreamSynchronize(c->stream)); ZK_HIP(c, hipFree(dptr)); }
     return ZK_OK;
 }
 
 int zk_upload(zk_ctx* c, void* dst_dev, const void* src_host, uint64_t bytes) {
     if (!c) return ZK_EINVAL;
+    enter(c);
     if (bytes == 0) return ZK_OK;
     ZK_HIP(c, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
@@ -348,6 +361,7 @@ int zk_upload(zk_ctx* c, void* dst_dev, const void* src_host, uint64_t bytes) {
 
 int zk_download(zk_ctx* c, void* dst_host, const void* src_dev, uint64_t bytes) {
     if (!c) return ZK_EINVAL;
+    enter(c);
     if (bytes == 0) return ZK_OK;
     ZK_HIP(c, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
@@ -356,6 +370,7 @@ int zk_download(zk_ctx* c, void* dst_host, const void* src_dev, uint64_t bytes) 
 
 int zk_copy(zk_ctx* c, void* dst_dev, const void* src_dev, uint64_t bytes) {
     if (!c) return ZK_EINVAL;
+    enter(c);
     if (bytes == 0) return ZK_OK;
     ZK_HIP(c, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, c->stream));
     return ZK_OK;

@@ -49,6 +49,11 @@ struct zk_ctx {
     std::string last_error;
     u64* dbg = nullptr;        // diagnostic stamp buffer (zk_debug_buffer), normally null
 
+    // multi-GPU: one RCCL communicator per context (comm.hip); world 1 / rank 0 until zk_comm_init
+    void* comm = nullptr;
+    int comm_world = 1, comm_rank = 0;
+    uint64_t comm_chunk_bytes = 0;      // bytes per message and round of zk_all_to_all_v (0 = 256 MiB; zk_tune, tests)
+
     // optional per-launch timing with HIP events on this stream (zk_profile_*)
     struct ProfRec { int tag; uint64_t bytes; hipEvent_t a, b; };
     bool profile = false;
@@ -58,6 +63,12 @@ struct zk_ctx {
 namespace zk {
 
 int fail(zk_ctx* c, int code, const char* fmt, ...);
+// HIP's current device is per host thread and other code in the process (torch.cuda.set_device, another ctx) may have
+// changed it: every C-ABI entry makes the context's device current before it allocates or launches.
+static inline void enter(zk_ctx* c) {
+    int d = -1;
+    if (c && (hipGetDevice(&d) != hipSuccess || d != c->device)) (void)hipSetDevice(c->device);
+}
 #define ZK_HIP(c, call)                                                                         \
     do {                                                                                        \
         hipError_t e__ = (call);                                                                \
@@ -123,6 +134,11 @@ int count_hist(zk_ctx* c, const void* counts, int count_bits, uint64_t n, uint64
 int codec_decode(zk_ctx* c, const u64* d_words, uint64_t nw, int delta, u64* d_out, uint64_t cap, uint64_t* n_out);
 int fastq_mask(zk_ctx* c, const u8* d_text, uint64_t n, uint32_t line_phase, u8* d_out, uint64_t* n_newlines);
 int codec_encode(zk_ctx* c, const u64* d_vals, uint64_t n, int delta, u64* d_words, uint64_t cap, uint64_t* n_words);
+int scan64_inclusive(zk_ctx* c, u64* d_v, uint64_t n);   // in place, asynchronous
+// partition.hip
+int hash_partition(zk_ctx* c, const u64* keys, const void* cnts, int count_bits, uint64_t n, int world, u64 seed, u64* ok, void* oc,
+                   uint64_t* offsets);
+int checksum_any(zk_ctx* c, const u64* keys, const void* cnts, int count_bits, uint64_t n, uint64_t sums[3]);
 // setops.hip
 int union_sum(zk_ctx* c, const u64* A, const void* cA, u64 nA, const u64* B, const void* cB, u64 nB, u64* ok, void* oc,
               int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);

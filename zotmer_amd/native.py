@@ -87,6 +87,16 @@ SIGNATURES = {
     "zk_parse_fasta": (_i, [_vp, _u64, _i, _pu64, _vp, _u64, _pu64, _pu64]),
     "zk_synth_reads": (_i, [_vp, _u64, _u64, _u64, _i, _u64, _u32, _u32, _vp]),
     "zk_checksum": (_i, [_vp, _vp, _vp, _u64, _pu64]),
+    "zk_checksum_counts": (_i, [_vp, _vp, _vp, _i, _u64, _pu64]),
+    "zk_synth_keys": (_i, [_vp, _u64, _u64, _u64, _i, _u64, _u64, _u64, _vp]),
+    "zk_synth_counts": (_i, [_vp, _u64, _vp, _u64, _vp]),
+    "zk_hash_partition": (_i, [_vp, _vp, _vp, _i, _u64, _i, _u64, _vp, _vp, _pu64]),
+    "zk_comm_unique_id": (_i, [_vp]),
+    "zk_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "zk_comm_destroy": (_i, [_vp]),
+    "zk_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "zk_all_to_all_v": (_i, [_vp, _vp, _pu64, _pu64, _vp, _pu64, _pu64, _i]),
+    "zk_allreduce_u64": (_i, [_vp, _pu64, _u64, _i]),
     "zk_stream_checksum": (_i, [_vp, _vp, _u64, _i, _pu64]),
 }
 
@@ -206,7 +216,9 @@ class Context:
     PROF_TAGS = {"hist_stream": 1, "hist_array": 2, "pass_stream": 3, "pass_keys": 4, "pass_pairs": 5, "rle": 6,
                  "union_sum": 7, "select": 8, "mirror": 9, "intersect": 10, "count_hist": 11}
 
-    def tune(self, sort_variant=None, pairs_variant=None, short_sort=None, side_div=None, xcd_group=None):
+    def tune(self, sort_variant=None, pairs_variant=None, short_sort=None, side_div=None, xcd_group=None, comm_chunk=None):
+        if comm_chunk is not None:
+            self._check(self.lib.zk_tune(self.h, 6, int(comm_chunk)))
         if xcd_group is not None:
             self._check(self.lib.zk_tune(self.h, 5, int(xcd_group)))
         if short_sort is not None:
@@ -381,7 +393,7 @@ class Context:
         pos = np.zeros(len(q), dtype=np.uint64)
         self._check(self.lib.zk_lower_bound(self.h, sorted_keys.ptr, sorted_keys.n, q.ctypes.data_as(_pu64), len(q),
                                             pos.ctypes.data_as(_pu64)))
-        return [int(p) for p in pos]
+        return pos if isinstance(queries, np.ndarray) else [int(p) for p in pos]
 
     def project(self, ref, kmers, counts):
         ok, oc = self.empty(kmers.n, np.uint64), self.empty(kmers.n, np.uint64)
@@ -411,6 +423,81 @@ class Context:
         s = (C.c_uint64 * 3)()
         self._check(self.lib.zk_checksum(self.h, kmers.ptr, counts.ptr if counts is not None else None, kmers.n, s))
         return tuple(int(v) for v in s)
+
+    def checksum_counts(self, kmers, counts):
+        """zk_checksum over 32- or 64-bit counts"""
+        s = (C.c_uint64 * 3)()
+        self._check(self.lib.zk_checksum_counts(self.h, kmers.ptr, counts.ptr if counts is not None else None,
+                                                counts.dtype.itemsize * 8 if counts is not None else 64, kmers.n, s))
+        return tuple(int(v) for v in s)
+
+    def synth_set(self, seed, first, count, key_bits, mul=1, add=0, mod=1 << 62, counts=True):
+        """A synthetic sorted k-mer set (zotmer_amd/synth.py set_keys / set_counts): sorted distinct keys of the
+        affine pool walk, and geometric 64-bit counts.  -> (keys u64, counts u64 | None)"""
+        raw = self.empty(count, np.uint64)
+        self._check(self.lib.zk_synth_keys(self.h, int(seed), int(first), int(count), int(key_bits), int(mul), int(add), int(mod), raw.ptr))
+        k, _ = self.sort_count(raw, key_bits)
+        del raw
+        k = self.copy_of(k)
+        if not counts:
+            return k, None
+        c = self.empty(k.n, np.uint64)
+        self._check(self.lib.zk_synth_counts(self.h, int(seed), k.ptr, k.n, c.ptr))
+        return k, c
+
+    def copy_of(self, a):
+        """A right-sized copy of a (possibly oversized or borrowed) device array."""
+        out = self.empty(a.n, a.dtype)
+        if a.n:
+            self._check(self.lib.zk_copy(self.h, out.ptr, a.ptr, a.nbytes))
+            self.sync()
+        return out
+
+    def hash_partition(self, kmers, counts, world, seed=0, out=None):
+        """Stable split of a sorted table by the hash-range owner -> (kmers, counts | None, offsets[world + 1])."""
+        if out is None:
+            ok = self.empty(kmers.n, np.uint64)
+            oc = self.empty(kmers.n, counts.dtype) if counts is not None else None
+        else:
+            ok, oc = out
+        offs = (C.c_uint64 * (world + 1))()
+        self._check(self.lib.zk_hash_partition(self.h, kmers.ptr, counts.ptr if counts is not None else None,
+                                               counts.dtype.itemsize * 8 if counts is not None else 64, kmers.n, int(world), int(seed),
+                                               ok.ptr, oc.ptr if oc is not None else None, offs))
+        return ok, oc, [int(v) for v in offs]
+
+    # ---- multi-GPU seam (zk_comm_*: RCCL bound by the library itself) -----------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_uint8 * 128)()
+        rc = load().zk_comm_unique_id(buf)
+        if rc != ZK_OK:
+            raise ZotkError(rc, "zk_comm_unique_id failed (RCCL not loadable?)")
+        return bytes(buf)
+
+    def comm_init(self, world, rank, uid):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._check(self.lib.zk_comm_init(self.h, int(world), int(rank), buf))
+
+    def comm_destroy(self):
+        self._check(self.lib.zk_comm_destroy(self.h))
+
+    def comm_info(self):
+        w, r = C.c_int(1), C.c_int(0)
+        self._check(self.lib.zk_comm_info(self.h, C.byref(w), C.byref(r)))
+        return w.value, r.value
+
+    def all_to_all_v(self, send_ptr, send_off, send_cnt, recv_ptr, recv_off, recv_cnt, elem_bytes):
+        W = len(send_cnt)
+        arr = lambda v: (C.c_uint64 * W)(*[int(x) for x in v])
+        self._check(self.lib.zk_all_to_all_v(self.h, send_ptr, arr(send_off), arr(send_cnt), recv_ptr, arr(recv_off), arr(recv_cnt),
+                                             int(elem_bytes)))
+
+    def allreduce_u64(self, vals, op=0):
+        a = np.ascontiguousarray(vals, dtype=np.uint64).copy()
+        if a.size:
+            self._check(self.lib.zk_allreduce_u64(self.h, a.ctypes.data_as(_pu64), a.size, int(op)))
+        return a
 
     def stream_checksum(self, stream, K):
         s = (C.c_uint64 * 7)()

@@ -90,6 +90,58 @@ def fastq_text(seed, first, count, L, **kw):
                    for k, s in enumerate(read_strings(seed, first, count, L, **kw)))
 
 
+# ---- synthetic sorted k-mer sets (BASELINE configs 3 and 4); the HIP version is csrc/partition.hip ----------
+
+def set_keys_raw(seed, first, count, key_bits, mul=1, add=0, mod=1 << 62):
+    """Element first+i of an affine walk through a pool of `mod` random keys: rnd(seed, 7, (mul*(first+i)+add) % mod)
+    masked to key_bits -- distinct pool indices while first+i < mod and gcd(mul, mod) == 1 (a draw without
+    replacement).  Unsorted, may hold the odd duplicate value."""
+    i = np.arange(first, first + count, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        j = (np.uint64(mul) * i + np.uint64(add)) % np.uint64(mod)
+    mask = np.uint64((1 << key_bits) - 1) if key_bits < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    return rnd(seed, 7, j) & mask
+
+
+def set_keys(seed, first, count, key_bits, **kw):
+    """The sorted distinct keys of set_keys_raw."""
+    return np.unique(set_keys_raw(seed, first, count, key_bits, **kw))
+
+
+def set_counts(seed, keys):
+    """Geometric counts (mean 8) in integer arithmetic: successive 3-bit groups of rnd(seed, 8, key) are trials that
+    stop with probability 1/8; a word whose 21 groups all fail is re-mixed (at most 8 words)."""
+    h = rnd(seed, 8, np.asarray(keys, dtype=np.uint64))
+    cnt = np.ones(len(h), dtype=np.uint64)
+    done = np.zeros(len(h), dtype=bool)
+    for _ in range(8):
+        for g in range(21):
+            stop = ((h >> np.uint64(3 * g)) & np.uint64(7)) == 0
+            newly = stop & ~done
+            done |= newly
+            cnt += (~done).astype(np.uint64)
+        h = mix64(h)
+    return cnt
+
+
+# config 3: two sets of 100 M 50-bit keys, half of them shared = two windows of one key sequence
+CONFIG3 = dict(n=100_000_000, key_bits=50, seed=1, first_a=0, first_b=50_000_000)
+# config 4: 64 sets of 50 M keys drawn without replacement from a shared pool of 200 M, geometric counts (mean 8);
+# set s walks the pool with stride CONFIG4["mul"][s % 8] from offset 3 125 000 * s
+CONFIG4 = dict(sets=64, n=50_000_000, pool=200_000_000, key_bits=50, seed=100,
+               mul=[1, 3, 7, 11, 13, 17, 19, 23])
+
+
+def config4_set_args(s, scale=1.0):
+    """zk_synth_keys / set_keys arguments of set s of config 4 (scale < 1 shrinks pool and sets together)."""
+    n, pool = int(CONFIG4["n"] * scale), int(CONFIG4["pool"] * scale)
+    pool |= 1                                             # odd pool size: every stride of the table is coprime to it
+    while any(pool % m == 0 for m in CONFIG4["mul"] if m > 1):
+        pool += 2
+    return dict(seed=CONFIG4["seed"], first=0, count=n, key_bits=CONFIG4["key_bits"], mul=CONFIG4["mul"][s % 8],
+                add=(pool // 64) * s, mod=pool)
+
+
 # The named configurations of BASELINE.json / SURVEY.md section 8(d).
 CONFIGS = {
     # name: reads, L, K, genome, sub rate, N rate
