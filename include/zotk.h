@@ -243,6 +243,13 @@ int zk_codec64_decode(const uint64_t* words, uint64_t nw, int delta, uint64_t* o
 int zk_codec64_encode_dev(zk_ctx* ctx, const uint64_t* d_vals, uint64_t n, int delta, uint64_t* d_words, uint64_t cap, uint64_t* n_words);
 int zk_codec64_decode_dev(zk_ctx* ctx, const uint64_t* d_words, uint64_t nw, int delta, uint64_t* d_out, uint64_t cap, uint64_t* n_out);
 
+/* files.undelta (library/files.py:100-110) of a PIECE of a delta stream: in-place inclusive prefix sum of the decoded
+ * deltas, continued from `base` (the last k-mer before the piece; 0 for the first piece).  With zk_add_u64 (v[i] += x,
+ * asynchronous) this lets every rank of a multi-GPU `zot dist` decode its own contiguous range of the words of a
+ * 'kmers' member: scan from 0, exchange the pieces' totals, add the base. */
+int zk_undelta(zk_ctx* ctx, uint64_t* d_vals, uint64_t n, uint64_t base);
+int zk_add_u64(zk_ctx* ctx, uint64_t* d_vals, uint64_t n, uint64_t x);
+
 /* file.readFastq / file.readFasta (library/file.py:19-52) as chunked text -> base stream converters.
  * state: 4 words, zero before the first chunk, state[1] = records seen.  Feed text; *consumed says how
  * much was used (present the rest again in front of the next chunk); final != 0 on the last chunk.

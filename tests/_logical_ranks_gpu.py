@@ -1,0 +1,162 @@
+"""Run by tests/test_gpu_multigpu.py in its own process (torch first, as the commands do under torch.distributed.run).
+
+BASELINE config 4 in miniature on ONE device: 64 synthetic sets (zotmer_amd/synth.py config 4 generator, scaled down)
+merged over 8 LOGICAL ranks -- eight threads, each with its own zk_ctx on the same GPU, running the PRODUCT functions of
+zotmer_amd/parallel.py (Exchange.merge_sets / dist_pair / gather_to_root with GpuOps, i.e. zk_merge_n, zk_lower_bound,
+zk_hash_partition, zk_project_dedupe, zk_split on the device).  Only the transport is a stand-in: `ThreadComm` moves the
+pieces with device-to-device copies and reduces integers under a barrier, where the real thing calls RCCL.  Compared
+bit for bit with one oracle merge of all 64 sets, for both owner functions; dist at K = 25 and projected to K = 12.
+"""
+import os
+import sys
+import threading
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import zkoracle as zo                 # noqa: E402
+from zotmer_amd import native, parallel, synth    # noqa: E402
+
+W = 8
+SCALE = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0004        # 64 sets x 20 000 keys from a pool of 80 000
+K = 25
+
+
+class ThreadComm:
+    """The transport of parallel.Exchange for W threads of one process."""
+    name = "threads"
+    shared = None
+
+    def __init__(self, rank):
+        self.world, self.rank = W, rank
+        self.device = "cuda"
+
+    @classmethod
+    def setup(cls):
+        cls.shared = dict(bar=threading.Barrier(W), slots=[None] * W, err=[])
+
+    def _gather(self, obj):
+        s = self.shared
+        s["slots"][self.rank] = obj
+        s["bar"].wait()
+        out = list(s["slots"])
+        s["bar"].wait()
+        return out
+
+    def all_reduce(self, vals, op="sum"):
+        as_array = isinstance(vals, np.ndarray)
+        a = np.ascontiguousarray(vals, dtype=np.uint64) if as_array else np.array([int(v) & parallel.M64 for v in vals], dtype=np.uint64)
+        parts = self._gather(a)
+        with np.errstate(over="ignore"):
+            r = parts[0].copy()
+            for p in parts[1:]:
+                r = np.maximum(r, p) if op == "max" else r + p
+        return r if as_array else [int(v) for v in r]
+
+    def all_gather_object(self, obj):
+        return self._gather(obj)
+
+    def barrier(self):
+        self.shared["bar"].wait()
+
+    def all_to_all_v(self, out_t, in_t, recv, send, send_off, recv_off):
+        torch.cuda.synchronize()
+        views = self._gather((in_t, list(send), list(send_off)))
+        for src in range(W):
+            t, s_cnt, s_off = views[src]
+            n = s_cnt[self.rank]
+            assert n == recv[src]
+            if n:
+                out_t[recv_off[src]:recv_off[src] + n].copy_(t[s_off[self.rank]:s_off[self.rank] + n])
+        torch.cuda.synchronize()
+        self.shared["bar"].wait()
+
+
+def make_sets():
+    sets = []
+    for s in range(64):
+        a = synth.config4_set_args(s, SCALE)
+        k = synth.set_keys(a["seed"], a["first"], a["count"], a["key_bits"], mul=a["mul"], add=a["add"], mod=a["mod"])
+        sets.append((k, synth.set_counts(a["seed"], k)))
+    return sets
+
+
+def worker(rank, owner, host_sets, results):
+    try:
+        ctx = native.Context(0)
+        comm = ThreadComm(rank)
+        ex = parallel.Exchange(ctx, None, K, owner=owner, seed=11, comm=comm)
+        # the sets of this rank, generated ON THE DEVICE (zk_synth_keys / zk_synth_counts) and checked against synth.py
+        mine = []
+        for s in range(rank, 64, W):
+            a = synth.config4_set_args(s, SCALE)
+            k, c = ctx.synth_set(a["seed"], a["first"], a["count"], a["key_bits"], mul=a["mul"], add=a["add"], mod=a["mod"])
+            assert np.array_equal(k.to_host(), host_sets[s][0]) and np.array_equal(c.to_host(), host_sets[s][1]), "device generator"
+            mine.append((k, c))
+        k, c, _ = ctx.merge_n(mine)                                    # 8 sets per rank
+        kt, ct, n = ex.ops.to_tensors(k, c)
+        sums_in = [0, 0, 0]
+        for sk, sc in mine:
+            for i, v in enumerate(ctx.checksum_counts(sk, sc)):
+                sums_in[i] = (sums_in[i] + v) & parallel.M64
+        res = ex.merge_sets(kt, ct, n)
+        assert ex.verify_global(res["k"], res["c"], sums_in), "checksum of checksums"
+        owned = res["k"].n
+        gk, gc = ex.gather_to_root(res["k"], res["c"])
+        out = dict(owned=owned, acgt=res["acgt"], hist=res["hist"], n_global=res["n_global"])
+        if rank == 0:
+            out["k"], out["c"] = gk.to_host(), gc.to_host()
+        # dist: sets 0 and 1, position-sharded over the ranks, at K = 25 and projected to K = 12
+        for kk in (25, 12):
+            exd = parallel.Exchange(ctx, None, kk, owner=owner, seed=11, comm=comm)
+            pieces = []
+            for s in (0, 1):
+                ch = np.array_split(host_sets[s][0], W)[rank]
+                pieces.append((torch.from_numpy(ch.view(np.int64).copy()).cuda() if len(ch) else torch.empty(1, dtype=torch.int64, device="cuda"), len(ch)))
+            abc, sizes = exd.dist_pair(pieces[0][0], pieces[0][1], pieces[1][0], pieces[1][1], shift=2 * (K - kk))
+            out["abc%d" % kk], out["sz%d" % kk] = abc, sizes
+        results[rank] = out
+        ctx.close()
+    except BaseException as e:          # noqa: BLE001
+        import traceback
+        ThreadComm.shared["err"].append("rank %d: %s" % (rank, traceback.format_exc()))
+        try:
+            ThreadComm.shared["bar"].abort()
+        except Exception:
+            pass
+        raise e
+
+
+def main():
+    host_sets = make_sets()
+    zs, zc, zacgt = zo.merge_n(K, host_sets)
+    hv, hf = zo.hist(zc)
+    for owner in ("range", "hash"):
+        ThreadComm.setup()
+        results = [None] * W
+        th = [threading.Thread(target=worker, args=(r, owner, host_sets, results)) for r in range(W)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not ThreadComm.shared["err"], "\n".join(ThreadComm.shared["err"])
+        r0 = results[0]
+        assert np.array_equal(r0["k"], zs), owner + ": merged k-mers differ from the oracle"
+        assert np.array_equal(r0["c"], zc), owner + ": merged counts differ from the oracle"
+        sizes = [r["owned"] for r in results]
+        assert sum(sizes) == len(zs) and max(sizes) <= 1.2 * len(zs) / W, (owner, sizes)
+        for r in results:
+            assert [int(v) for v in r["acgt"]] == [int(v) for v in zacgt]
+            assert r["hist"] == {int(a): int(b) for a, b in zip(hv, hf)}
+            assert r["n_global"] == len(zs)
+            for kk in (25, 12):
+                pa, pb = zo.project_dedupe(host_sets[0][0], 2 * (K - kk)), zo.project_dedupe(host_sets[1][0], 2 * (K - kk))
+                assert tuple(int(v) for v in r["abc%d" % kk]) == zo.split(pa, pb), (owner, kk)
+                assert tuple(int(v) for v in r["sz%d" % kk]) == (len(pa), len(pb))
+        print("LOGICAL-RANKS-OK", owner, len(zs), sizes)
+
+
+if __name__ == "__main__":
+    main()

@@ -216,6 +216,26 @@ def test_config1_digest():
     assert [c / tot for c in r["acgt"]] == g["meta"]["acgt"]
 
 
+def test_python_restatement_config1_digest():
+    """oracle/py_restatement.py (the pure-Python 'reference CPU path' bench.py times) on config 1
+    against what the reference itself produced: both encoded streams byte for byte (sha256), hist, acgt, reads."""
+    import struct
+    from oracle import py_restatement as pr
+    g = G.load_json("config1_digest")
+    r = pr.kmerize(g["K"], G.synth_reads(g))
+    assert len(r["kmers"]) == g["n"] and sum(r["counts"]) == g["sum_counts"] and r["instances"] == g["sum_counts"]
+    assert hashlib.sha256(struct.pack("<%dQ" % len(r["kmers"]), *r["kmers"])).hexdigest() == g["sha256_kmers"]
+    assert hashlib.sha256(r["kmers_bytes"]).hexdigest() == g["sha256_raw_kmers"]
+    assert hashlib.sha256(r["counts_bytes"]).hexdigest() == g["sha256_raw_counts"]
+    assert (len(r["kmers_bytes"]), len(r["counts_bytes"])) == (g["len_raw_kmers"], g["len_raw_counts"])
+    assert {str(k): v for k, v in r["hist"].items()} == g["meta"]["hist"]
+    assert r["acgt"] == g["meta"]["acgt"] and r["reads"] == g["meta"]["reads"]
+    # the flush path (KmerAccumulator2 merges a new sorted buffer into the table) gives the same arrays
+    r2 = pr.kmerize(g["K"], G.synth_reads(g)[:3000], flush_at=100_000)
+    r1 = pr.kmerize(g["K"], G.synth_reads(g)[:3000])
+    assert r1["kmers"] == r2["kmers"] and r1["counts"] == r2["counts"]
+
+
 # ---- next-row commands (f3): jaccard / project / sample ------------------------------------------------
 
 def _rename(ref, names_new):

@@ -52,7 +52,7 @@ def main(argv):
             d = ctx.upload_stream(seq + b"\n")
             k, c, _ = ctx.kmerize(d, K, native.KMERIZE_BOTH)
             names.append(nm.split()[0])
-            recs.append(engine._compact(ctx, k, c)[0])
+            recs.append(ctx.copy_of(k))
         print(len(recs))
         _pairs(names, lambda i: recs[i], opts["-a"], p)
         return

@@ -53,6 +53,7 @@ def main(argv):
         raise SystemExit("zot kmerize: k must be between 1 and 32")
     verbose = opts["-v"]
 
+    dist, world, rank = engine.distributed()        # one process per GPU under torch.distributed.run
     ctx = engine.context()
     subsample = None
     if opts["-D"] is not None:                      # kmerize.py:469-478
@@ -64,12 +65,16 @@ def main(argv):
             d = ctx.upload_stream(seq + b"\n")
             ks, _ = ctx.encode(d, K, both=True)
             acc.append(ks.to_host())
-        b = np.unique(np.concatenate(acc)) if acc else np.empty(0, np.uint64)
-        baits = ctx.upload(b)
+        if acc:                                     # sorted distinct bait k-mers: device sort + run-length (zk_sort_count)
+            allk = ctx.upload(np.concatenate(acc))
+            baits = ctx.copy_of(ctx.sort_count(allk, 2 * K)[0])
+        else:
+            baits = ctx.upload(np.empty(0, np.uint64))
 
     table = engine.KmerTable(ctx, K, subsample=subsample, baits=baits)
     batch = engine.batch_bytes_for(ctx, (int(opts["-m"]) << 20) if opts["-m"] is not None else None)
     n_reads = 0
+    n_batch = 0                                     # multi-GPU: rank r counts batches r, r + world, ... (reads are independent)
     timing = os.environ.get("ZOT_TIMING") == "1"
     t_parse = t_gpu = 0.0
     t0 = time.perf_counter()
@@ -79,7 +84,9 @@ def main(argv):
             for stream, recs in seqio.base_stream_batches([path], batch_bytes=batch):
                 t1 = time.perf_counter()
                 t_parse += t1 - t0
-                table.add_stream(stream)
+                if n_batch % world == rank:
+                    table.add_stream(stream)
+                n_batch += 1
                 t0 = time.perf_counter()
                 t_gpu += t0 - t1
                 n_reads += recs                     # kmerize.py:527: every record counts
@@ -89,7 +96,9 @@ def main(argv):
             for text, phase, recs in seqio.fastq_text_batches(path, batch_bytes=batch):
                 t1 = time.perf_counter()
                 t_parse += t1 - t0
-                table.add_fastq_text(text, phase)
+                if n_batch % world == rank:
+                    table.add_fastq_text(text, phase)
+                n_batch += 1
                 t0 = time.perf_counter()
                 t_gpu += t0 - t1
                 n_reads += recs
@@ -99,6 +108,10 @@ def main(argv):
         sys.stderr.write("\n")
 
     kmers, counts, hist = table.device_result()
+    if dist is not None:
+        kmers, counts, hist = _gather_distributed(ctx, dist, K, table, kmers, counts)
+        if rank != 0:
+            return
     with KmerSet(out, "w") as z:                    # kmerize.py:541-561; delta + codec64 done on the device
         vectors.device_write_kmers_and_counts(ctx, z, kmers, counts)
         total = float(sum(table.acgt))
@@ -111,6 +124,23 @@ def main(argv):
     if timing:
         sys.stderr.write("zot kmerize: read+parse %.2f s, upload+count %.2f s, hist+encode+write %.2f s\n"
                          % (t_parse, t_gpu, time.perf_counter() - t0))
+
+
+def _gather_distributed(ctx, dist, K, table, kmers, counts):
+    """The ranks' tables meet in one exchange by k-mer owner (zotmer_amd/parallel.py), acgt is all-reduced, and rank 0
+    gathers the owned pieces to write the one output file."""
+    from zotmer_amd import parallel
+    comm = parallel.make_comm(ctx, dist)
+    ex = parallel.Exchange(ctx, dist, K, owner=os.environ.get("ZOT_OWNER", "range"), comm=comm)
+    kt, ct, n = ex.ops.to_tensors(kmers, counts)
+    if ex.owner == "range":
+        ex.balanced_cuts([(kt, n)])
+    k, c = ex.exchange_and_merge(kt, ct, n)
+    table.acgt = comm.all_reduce(table.acgt)
+    gk, gc = ex.gather_to_root(k, c)
+    if comm.rank != 0:
+        return None, None, None
+    return gk, gc, ctx.hist(gc)
 
 
 if __name__ == "__main__":

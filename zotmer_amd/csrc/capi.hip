@@ -267,6 +267,21 @@ int zk_codec64_decode_dev(zk_ctx* c, const uint64_t* d_words, uint64_t nw, int d
     return codec_decode(c, (const u64*)d_words, nw, delta, (u64*)d_out, cap, n_out);
 }
 
+int zk_undelta(zk_ctx* c, uint64_t* d_vals, uint64_t n, uint64_t base) {
+    ZK_ARGS(c, n == 0 || d_vals);
+    if (n == 0) return ZK_OK;
+    arena_reset(c);
+    ZK_TRY(add_u64(c, (u64*)d_vals, 1, base));
+    ZK_TRY(scan64_inclusive(c, (u64*)d_vals, n));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    return check_device_error(c);
+}
+
+int zk_add_u64(zk_ctx* c, uint64_t* d_vals, uint64_t n, uint64_t x) {
+    ZK_ARGS(c, n == 0 || d_vals);
+    return add_u64(c, (u64*)d_vals, n, x);
+}
+
 int zk_fastq_mask(zk_ctx* c, const uint8_t* d_text, uint64_t n, uint32_t line_phase, uint8_t* d_stream, uint64_t* n_newlines) {
     ZK_ARGS(c, n_newlines && d_stream);
     arena_reset(c);
@@ -278,6 +293,7 @@ int zk_lower_bound(zk_ctx* c, const uint64_t* d_sorted, uint64_t n, const uint64
     if (m == 0) return ZK_OK;
     arena_reset(c);
     u64 *dq, *dp;
+    ZK_TRY(arena_require(c, 16ull * m + 4096, 16ull * m + 4096));
     ZK_TRY(arena_alloc(c, 8ull * m, (void**)&dq));
     ZK_TRY(arena_alloc(c, 8ull * m, (void**)&dp));
     ZK_HIP(c, hipMemcpyAsync(dq, queries, 8ull * m, hipMemcpyHostToDevice, c->stream));

@@ -157,6 +157,19 @@ int scan64_inclusive(zk_ctx* c, u64* d_v, uint64_t n) {
     return ZK_OK;
 }
 
+__global__ void add_u64_kernel(u64* __restrict__ v, u64 n, u64 x) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) v[i] += x;
+}
+
+// v[i] += x for i < n (asynchronous)
+int add_u64(zk_ctx* c, u64* d_v, uint64_t n, u64 x) {
+    if (n == 0 || x == 0) return ZK_OK;
+    u64 g = div_up(n, 256 * 8), mx = (u64)c->num_cus * 16;
+    hipLaunchKernelGGL(add_u64_kernel, dim3((u32)(g < mx ? g : mx)), dim3(256), 0, c->stream, d_v, (u64)n, x);
+    ZK_HIP(c, hipGetLastError());
+    return ZK_OK;
+}
+
 int codec_decode(zk_ctx* c, const u64* d_words, uint64_t nw, int delta, u64* d_out, uint64_t cap, uint64_t* n_out) {
     *n_out = 0;
     if (nw == 0) return ZK_OK;

@@ -265,6 +265,10 @@ static int union_sum_t(zk_ctx* c, const u64* A, const CT* cA, u64 nA, const u64*
     if (acgt_w) acgt_w[0] = acgt_w[1] = acgt_w[2] = acgt_w[3] = 0;
     if (nA + nB == 0) return ZK_OK;
     u64* part; u32 tiles;
+    if (c->arena_off == 0) {          // a direct call: size the workspace for the partition AND the acgt rows before handing any out
+        const uint64_t need = 40ull * (div_up(nA + nB, MRG_TILE) + 2) + 4096;
+        ZK_TRY(arena_require(c, need, need));
+    }
     ZK_TRY(make_partition(c, A, nA, B, nB, &part, &tiles));
     MergeState st;
     st.tiles = tiles;

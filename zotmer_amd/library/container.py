@@ -55,6 +55,20 @@ class Container:
             raise IOError("%s: member %r is truncated" % (self.path, name))
         return data
 
+    def member_size(self, name):
+        return self.toc[name][-1][1]
+
+    def read_range(self, name, start, length):
+        """`length` bytes of the latest version of a member, from byte `start` of the member."""
+        off, total = self.toc[name][-1]
+        if start < 0 or length < 0 or start + length > total:
+            raise ValueError("range outside member %r" % name)
+        self._f.seek(off + start)
+        data = self._f.read(length)
+        if len(data) != length:
+            raise IOError("%s: member %r is truncated" % (self.path, name))
+        return data
+
     # -- writing ----------------------------------------------------------------------------
     def add(self, name, data):
         """Append a member given as bytes (or anything with the buffer protocol)."""

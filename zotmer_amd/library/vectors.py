@@ -138,3 +138,27 @@ def device_read_kmers_and_counts(ctx, z):
     if k.n != c.n:
         raise CodecError("k-mer and count vectors differ in length (%d vs %d)" % (k.n, c.n))
     return k, c
+
+
+def device_read_kmers_shard(ctx, z, rank, world, comm):
+    """This rank's contiguous piece of a sorted 'kmers' member (position-sharded: rank order = value order) for the
+    multi-GPU `zot dist`.  codec64 words decode independently, only the delta transform chains them: every rank decodes
+    words [rank, rank + 1) * nw / world, sums its own deltas, the sums are exchanged, and the total of the earlier ranks
+    is the base the piece continues from (files.undelta, zotmer/library/files.py:100-110)."""
+    nw = z.member_size("kmers") // 8
+    w0, w1 = nw * rank // world, nw * (rank + 1) // world
+    if w1 > w0:
+        words = np.frombuffer(z.read_range("kmers", 8 * w0, 8 * (w1 - w0)), dtype="<u8")
+        vals = _check_codec(ctx.codec_decode, ctx.upload(words), False)
+        ctx.undelta(vals, 0)
+        last = int(vals.view(1, vals.n - 1).to_host()[0]) if vals.n else 0
+    else:
+        vals, last = ctx.empty(0, np.uint64), 0
+    sums = [0] * world
+    sums[rank] = last
+    sums = comm.all_reduce(sums)
+    base = sum(sums[:rank]) & 0xFFFFFFFFFFFFFFFF
+    if base and vals.n:
+        ctx.add_u64(vals, base)
+        ctx.sync()
+    return vals

@@ -83,6 +83,8 @@ SIGNATURES = {
     "zk_codec64_encode_dev": (_i, [_vp, _vp, _u64, _i, _vp, _u64, _pu64]),
     "zk_codec64_decode_dev": (_i, [_vp, _vp, _u64, _i, _vp, _u64, _pu64]),
     "zk_fastq_mask": (_i, [_vp, _vp, _u64, _u32, _vp, _pu64]),
+    "zk_undelta": (_i, [_vp, _vp, _u64, _u64]),
+    "zk_add_u64": (_i, [_vp, _vp, _u64, _u64]),
     "zk_parse_fastq": (_i, [_vp, _u64, _i, _pu64, _vp, _u64, _pu64, _pu64]),
     "zk_parse_fasta": (_i, [_vp, _u64, _i, _pu64, _vp, _u64, _pu64, _pu64]),
     "zk_synth_reads": (_i, [_vp, _u64, _u64, _u64, _i, _u64, _u32, _u32, _vp]),
@@ -380,6 +382,15 @@ class Context:
         out = self.empty(n_values, np.uint64)
         self._check(self.lib.zk_codec64_decode_dev(self.h, words.ptr, words.n, int(delta), out.ptr, int(n_values), C.byref(n)))
         return out.view(n.value)
+
+    def undelta(self, vals, base=0):
+        """in-place prefix sum of decoded k-mer deltas, continued from `base` (files.undelta)"""
+        self._check(self.lib.zk_undelta(self.h, vals.ptr, vals.n, int(base) & 0xFFFFFFFFFFFFFFFF))
+        return vals
+
+    def add_u64(self, vals, x):
+        self._check(self.lib.zk_add_u64(self.h, vals.ptr, vals.n, int(x) & 0xFFFFFFFFFFFFFFFF))
+        return vals
 
     def fastq_mask(self, text, line_phase=0):
         """FASTQ text on the device -> (base stream of the same length, number of newlines)."""
