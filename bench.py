@@ -1,25 +1,31 @@
 #!/usr/bin/env python3
 """
-bench.py -- `zot kmerize` K=25 on synthetic 150 bp reads, the metric of BASELINE.json.
+bench.py -- `zot kmerize` K=25 on synthetic 150 bp reads, the metric of BASELINE.json, plus the other single-GPU
+configurations as `extra` blocks of the same JSON line.
 
   python bench.py --gpus N --steps K --warmup W
   (N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step is one whole kmerize of the batch: base stream resident in HBM -> sorted distinct k-mers
-of both strands + counts in HBM (hist and acgt included), i.e. zk_kmerize + zk_hist through the
-C-ABI.  At N = 1 the workload is BASELINE config 2 (50 M x 150 bp genome-sampled reads, K = 25).
-At N > 1 every rank kmerizes its own 50 M reads (weak scaling) and the per-rank tables are then
-exchanged by k-mer value range with one RCCL all-to-all and union-summed, so that each rank ends
-up owning one contiguous range of the global table.
+Headline.  A step is one whole kmerize of the batch: base stream resident in HBM -> sorted distinct k-mers of both
+strands + counts in HBM (hist and acgt included), i.e. zk_kmerize + zk_hist through the C-ABI.  At N = 1 the workload
+is BASELINE config 2 (50 M x 150 bp genome-sampled reads, K = 25).  At N > 1 every rank kmerizes its own 50 M reads
+(weak scaling) and the per-rank tables are then exchanged by k-mer owner (balanced value ranges by default) with one
+RCCL all-to-all and union-summed, so that each rank ends up owning one piece of the global table.
 
-One JSON line on stdout (rank 0).  `value` counts emitted k-mer instances (both strands, the unit
-the reference counts at commands/kmerize.py:523-525) per second of wall time over the timed steps.
-`roofline` is the dominant kernel (one radix-sort pass over the key array): algorithmic 16 B/key
-over its mean launch time, measured with HIP events on the library's own stream.  `cpu_baseline` is
-the CPU oracle (a single-core C restatement of the reference algorithm) on a bounded sample of the
-same reads.
+`value` counts emitted k-mer instances (both strands, the unit the reference counts at commands/kmerize.py:523-525) per
+second of wall time over the timed steps.  `roofline` is the dominant kernel (one radix-sort pass over the key array):
+algorithmic 16 B/key over its mean launch time, measured with HIP events on the library's own stream.  The result of
+the last timed step is verified outside the timed region (order-free checksums of the table against the same sums taken
+straight from the base stream; `verified_checksums`).  `cpu_baseline`: the C oracle on one core on a prefix of the same
+reads, and the pure-Python restatement of the reference path on BASELINE config 1.
+
+`extra` (N = 1): config 3 (`zot dist` on two 100 M-k-mer sets), one GPU's share of config 4 (merge of 8 x 50 M-k-mer
+sets), one GPU's share of config 5 (K = 31, 37.5 M reads) and config 2 again with the base stream starting in pinned
+host memory (H2D inside the timed region).  N > 1: `zot merge` (8 sets per GPU, config 4 at N = 8) and `zot dist`
+(config 3 sharded over the GPUs) through the product functions of zotmer_amd/parallel.py.  Every block is verified.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy reaches
+M64 = (1 << 64) - 1
 
 
 def model_bytes(n_stream_bytes, instances, unique, K):
@@ -39,25 +46,44 @@ def model_bytes(n_stream_bytes, instances, unique, K):
     return n_stream_bytes + 8 * instances + (1 + 2 * P) * 8 * instances + 8 * instances + 12 * unique
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources: a committed PMC profile is only quoted while the kernels are the profiled ones"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "zotmer_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
 def measured_traffic(kernel_substr, n_keys_now):
-    """HBM bytes per launch of the dominant kernel from the committed PMC runs of THIS command
-    (profiles/r01_config2_pipeline/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-    passes, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950; tools/collect_traffic.py).  PMC
-    counters cannot be read from inside the timed run, so the figure is taken from that profile and only
-    reported when the workload (number of keys per launch) is the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_config2_pipeline", "pmc_traffic.json")
-    try:
-        d = json.load(open(path))
-    except Exception:
-        return None
-    for name, v in d.items():
-        if kernel_substr in name and abs(v.get("n_keys", 0) - n_keys_now) <= 0.001 * max(n_keys_now, 1):
-            return v["traffic_bytes_per_launch"]
-    return None
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC profile of THIS command
+    (profiles/*/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled as
+    MI355X_MICROARCH.md prescribes for gfx950; tools/collect_traffic.py).  PMC counters cannot be read from inside the
+    timed run, so the figure is only quoted when the profile was taken from these very kernel sources (source hash) and
+    the same number of keys per launch; otherwise null."""
+    prof = os.path.join(ROOT, "profiles")
+    best = None
+    for sub in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
+        path = os.path.join(prof, sub, "pmc_traffic.json")
+        if os.path.exists(path):
+            try:
+                d = json.load(open(path))
+            except Exception:
+                continue
+            if d.get("_kernel_source_sha256") != kernel_source_hash():
+                continue
+            for name, v in d.items():
+                if isinstance(v, dict) and kernel_substr in name and abs(v.get("n_keys", 0) - n_keys_now) <= 0.001 * max(n_keys_now, 1):
+                    best = dict(bytes=v["traffic_bytes_per_launch"], profile="profiles/%s/pmc_traffic.json" % sub)
+    return best
 
 
 def cpu_baseline(cfg, seed, budget_s=12.0):
-    """Single-core CPU oracle on a prefix of the same reads, sized to about budget_s seconds."""
+    """(a) single-core C oracle on a prefix of the same reads, sized to about budget_s seconds; (b) the pure-Python
+    restatement of the reference path on BASELINE config 1."""
+    from oracle import py_restatement as pr
     from oracle import zkoracle as zo
     from zotmer_amd import synth
     kw = dict(genome=cfg["genome"], sub_thr=synth.frac32(cfg["sub"]), n_thr=synth.frac32(cfg["n"]))
@@ -74,9 +100,258 @@ def cpu_baseline(cfg, seed, budget_s=12.0):
     t, inst = run(20000)
     n = int(min(max(20000 * budget_s / max(t, 1e-3), 20000), 2_000_000))
     t, inst = run(n)
-    return {"value": inst / t / 1e9, "unit": "Gk-mers/s", "cores": 1, "kind": "port",
-            "sample": "first %d of the %d reads (same generator, same K), C oracle oracle/zk_oracle.c: per-read window loop, "
-                      "MSD radix + qsort, RLE merge; %.1f s" % (n, cfg["reads"], t)}
+    out = {"value": inst / t / 1e9, "unit": "Gk-mers/s", "cores": 1, "kind": "port",
+           "sample": "first %d of the %d reads (same generator, same K), C oracle oracle/zk_oracle.c: per-read window loop, "
+                     "MSD radix + qsort, RLE merge; %.1f s" % (n, cfg["reads"], t)}
+    c1 = synth.CONFIGS["config1"]
+    reads = synth.read_strings(seed, 0, c1["reads"], c1["L"], genome=c1["genome"], sub_thr=synth.frac32(c1["sub"]), n_thr=synth.frac32(c1["n"]))
+    t0 = time.perf_counter()
+    r = pr.kmerize(c1["K"], reads)
+    t1 = time.perf_counter() - t0
+    out["python_restatement"] = {"value": r["instances"] / t1 / 1e9, "unit": "Gk-mers/s", "cores": 1, "kind": "python-restatement",
+                                 "sample": "BASELINE config 1 (%d x %d bp, K = %d) whole, CPython %d.%d, oracle/py_restatement.py: per-read window "
+                                           "loop, bucket + list.sort, RLE merge, delta + codec64 (checked against the reference's digests in "
+                                           "tests/test_oracle_golden.py); %.1f s" % (c1["reads"], c1["L"], c1["K"], sys.version_info[0],
+                                                                                    sys.version_info[1], t1)}
+    return out
+
+
+def timed(ctx, fn, steps, warmup=1):
+    for _ in range(warmup):
+        fn()
+    ctx.sync()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = fn()
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / steps
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    kern = {n: dict(launches=v["launches"] // steps, ms_per_step=v["ms"] / steps, GBps=(v["bytes"] / 1e9) / (v["ms"] / 1e3) if v["ms"] else None)
+            for n, v in prof.items()}
+    return dt, r, kern
+
+
+def add_sums(a, b):
+    return tuple((x + y) & M64 for x, y in zip(a, b))
+
+
+# ---- extra blocks (N = 1) -------------------------------------------------------------------------------------
+def extra_config3(ctx, steps, scale):
+    """BASELINE config 3: `zot dist` on two sorted sets of 100 M 50-bit k-mers, half shared.  Timed: Measure.prep on both
+    files (zk_project_dedupe, identity at K = fK but the pass is what the command runs) + dist.split (zk_split).
+    Verified: (a) the generator's construction (two windows of one key sequence overlap in exactly half), (b) an
+    independent path -- concatenate, radix sort, run-length count: the number of runs of length 2 is |X & Y|."""
+    from zotmer_amd import synth
+    c3 = synth.CONFIG3
+    n = int(c3["n"] * scale)
+    ka, _ = ctx.synth_set(c3["seed"], 0, n, c3["key_bits"], counts=False)
+    kb, _ = ctx.synth_set(c3["seed"], n // 2, n, c3["key_bits"], counts=False)
+    pa, pb = ctx.empty(ka.n, np.uint64), ctx.empty(kb.n, np.uint64)
+
+    def prep_and_split():
+        import ctypes as C
+        m = C.c_uint64(0)
+        ctx._check(ctx.lib.zk_project_dedupe(ctx.h, ka.ptr, ka.n, 0, pa.ptr, pa.n, C.byref(m)))
+        ctx._check(ctx.lib.zk_project_dedupe(ctx.h, kb.ptr, kb.n, 0, pb.ptr, pb.n, C.byref(m)))
+        return ctx.split(pa, pb)
+
+    dt_all, abc, kern_all = timed(ctx, prep_and_split, steps)
+    dt, abc2, kern = timed(ctx, lambda: ctx.split(ka, kb), steps)
+    # independent check of a
+    cat = ctx.empty(ka.n + kb.n, np.uint64)
+    ctx._check(ctx.lib.zk_copy(ctx.h, cat.ptr, ka.ptr, ka.nbytes))
+    ctx._check(ctx.lib.zk_copy(ctx.h, cat.ptr + ka.nbytes, kb.ptr, kb.nbytes))
+    ctx.sync()
+    u, cnt = ctx.sort_count(cat, c3["key_bits"])
+    h = ctx.hist(cnt)
+    ok = abc == abc2 and h.get(2, 0) == abc[0] and set(h) <= {1, 2} and abc[0] + abc[1] == ka.n and abc[0] + abc[2] == kb.n \
+        and u.n == abc[0] + abc[1] + abc[2]
+    byts = 8 * (ka.n + kb.n)
+    ik = kern.get("intersect", {})
+    return {"workload": "BASELINE config 3: zot dist (jaccard) on two sorted sets of %d and %d 50-bit k-mers, %d shared" % (ka.n, kb.n, abc[0]),
+            "value": (ka.n + kb.n) / dt / 1e9, "unit": "Gk-mers/s", "ms_per_step": dt * 1e3, "ms_with_prep": dt_all * 1e3,
+            "abc": list(abc), "jaccard_distance": (abc[1] + abc[2]) / float(sum(abc)),
+            "verified": bool(ok), "verified_by": "sort + run-length count of the concatenation (hist[2] == a), set sizes",
+            "roofline": {"bound": "hbm", "kernel": "intersect_kernel (merge-path intersect count)", "algorithmic_bytes": byts,
+                         "achieved": (byts / 1e9) / (ik["ms_per_step"] / 1e3) if ik.get("ms_per_step") else None,
+                         "achieved_wall": byts / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (byts / 1e9) / (ik["ms_per_step"] / 1e3) / HBM_PEAK_GBS if ik.get("ms_per_step") else None},
+            "kernels": kern_all}
+
+
+def extra_config4_share(ctx, steps, scale):
+    """One GPU's share of BASELINE config 4: the k-way merge (mergeNinto) of 8 sets of 50 M k-mers with geometric 64-bit
+    counts drawn from the shared 200 M-key pool.  Verified by the checksum of checksums (sum over the inputs of
+    (count, key*count, murmer(key)*count) == the same sums over the merged set) and strict sortedness via the run-length
+    count of the output keys (every run has length 1)."""
+    from zotmer_amd import synth
+    sets, sums, total = [], (0, 0, 0), 0
+    for s in range(8):
+        a = synth.config4_set_args(s, scale)
+        k, c = ctx.synth_set(a["seed"], a["first"], a["count"], a["key_bits"], mul=a["mul"], add=a["add"], mod=a["mod"])
+        sets.append((k, c))
+        sums = add_sums(sums, ctx.checksum_counts(k, c))
+        total += k.n
+    ok_, oc_ = ctx.empty(total, np.uint64), ctx.empty(total, np.uint64)
+    dt, (mk, mc, acgt), kern = timed(ctx, lambda: ctx.merge_n(sets, out=(ok_, oc_)), steps)
+    got = ctx.checksum_counts(mk, mc)
+    chk = ctx.copy_of(mk)
+    _, runs = ctx.rle(chk)
+    hr = ctx.hist(runs)
+    ok = got == sums and hr == {1: mk.n} and sum(acgt) == sums[0]
+    byts = 3 * 16 * total + 16 * mk.n          # three merge levels read every pair once each (upper bound on the reads), + the output
+    return {"workload": "one GPU's share of BASELINE config 4: zot merge of 8 sets x %d k-mers (pool %d, geometric counts), 64-bit counts"
+                        % (sets[0][0].n, synth.config4_set_args(0, scale)["mod"]),
+            "value": total / dt / 1e9, "unit": "G (k-mer,count) pairs/s", "ms_per_step": dt * 1e3, "pairs_in": total, "unique_out": mk.n,
+            "verified": bool(ok), "verified_by": "checksum of checksums + run-length count of the output (strictly ascending)",
+            "roofline": {"bound": "hbm", "kernel": "union_sum_kernel<u64> x 3 tree levels", "algorithmic_bytes": byts,
+                         "achieved": byts / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / dt / 1e9 / HBM_PEAK_GBS},
+            "kernels": kern}
+
+
+def extra_config5_share(ctx, scale, synth, seed, batches=4):
+    """One GPU's share of BASELINE config 5 (K = 31, 300 M reads / 8 = 37.5 M x 150 bp from a 3.1 Gbp genome): at ~1.8x coverage
+    nearly every k-mer is distinct (about 6.8 G entries = 81 GB for one GPU), so the share is counted the way `zot kmerize`
+    does it -- library/engine.py KmerTable: batches, each sorted and counted on its own, tables union-summed pairwise.  Timed:
+    everything from the resident base stream of a batch to the final table + hist (allocation churn included); the synthetic
+    streams themselves are generated outside the timed region."""
+    from zotmer_amd.library import engine
+    c5 = synth.CONFIGS["config5"]
+    R5, L, K = int(c5["reads"] // 8 * scale), c5["L"], c5["K"]
+    per = -(-R5 // batches)
+    ctx.release_workspace()                      # config 2 left a 120 GB sort arena behind
+    table = engine.KmerTable(ctx, K)
+    want, t_total, inst = (0, 0, 0), 0.0, 0
+    for b in range(batches):
+        n = min(per, R5 - b * per)
+        if n <= 0:
+            break
+        d = ctx.synth_reads(seed, b * per, n, L, genome=c5["genome"], sub_thr=synth.frac32(c5["sub"]), n_thr=synth.frac32(c5["n"]))
+        want = add_sums(want, ctx.stream_checksum(d, K))
+        ctx.sync()
+        t0 = time.perf_counter()
+        table.add_device_stream(d)
+        ctx.sync()
+        t_total += time.perf_counter() - t0
+        del d
+    t0 = time.perf_counter()
+    k, c, h = table.device_result()
+    ctx.sync()
+    t_total += time.perf_counter() - t0
+    inst = table.instances
+    ok = ctx.checksum(k, c) == want and inst == want[0]
+    n_unique = k.n
+    mb = model_bytes(R5 * (L + 1), inst, n_unique, K)
+    del k, c, table
+    ctx.release_workspace()
+    return {"workload": "one GPU's share of BASELINE config 5: zot kmerize k=%d, %d x %d bp reads (300 M / 8), genome %d, in %d batches "
+                        "(library/engine.py KmerTable: per-batch sort + count, pairwise union-sum), hist included" % (K, R5, L, c5["genome"], batches),
+            "value": inst / t_total / 1e9, "unit": "Gk-mers/s", "ms_total": t_total * 1e3, "instances": inst, "unique": n_unique,
+            "verified": bool(ok), "verified_by": "order-free checksums of the final table == the sums taken from the base streams of all batches",
+            "roofline": {"bound": "hbm", "model_bytes": mb, "model_frac_of_peak": mb / t_total / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
+
+
+def extra_e2e_h2d(ctx, stream, K, steps, out_k, out_c):
+    """config 2 with the base stream starting in PINNED HOST memory -- the H2D copy is inside the timed
+    region (sequential: the sort needs the whole batch), the result stays in HBM."""
+    host = ctx.pinned(stream.n)
+    ctx._check(ctx.lib.zk_download(ctx.h, host.ptr, stream.ptr, stream.n))
+    dev = ctx.empty(stream.n, np.uint8)
+
+    def step():
+        ctx.upload_async(dev, host.ptr, stream.n)
+        k, c, st = ctx.kmerize(dev, K, 0, out=(out_k, out_c))
+        return k, c, st, ctx.hist(c)
+
+    t0 = time.perf_counter()
+    ctx.upload_async(dev, host.ptr, stream.n)
+    ctx.sync()
+    t_copy = time.perf_counter() - t0
+    dt, (k, c, st, h), kern = timed(ctx, step, steps)
+    ok = ctx.checksum(k, c) == ctx.stream_checksum(stream, K)
+    host.free()
+    return {"workload": "BASELINE config 2 end to end from pinned host memory: H2D of the %.2f GB base stream + kmerize + hist, result left in HBM"
+                        % (stream.n / 1e9), "value": st.n_instances / dt / 1e9, "unit": "Gk-mers/s", "ms_per_step": dt * 1e3,
+            "h2d_ms": t_copy * 1e3, "h2d_GBps": stream.n / t_copy / 1e9, "verified": bool(ok)}
+
+
+# ---- multi-GPU extras ------------------------------------------------------------------------------------------
+def extra_merge_multi(ctx, ex, steps, scale, world, rank):
+    """`zot merge` over the GPUs through parallel.Exchange.merge_sets: every rank merges its own 8 sets (sets rank, rank + world,
+    ... of 8 * world; BASELINE config 4 at world = 8), one exchange by k-mer owner, merge of the received pieces."""
+    from zotmer_amd import synth
+    sets, sums, total = [], (0, 0, 0), 0
+    for j in range(8):
+        a = synth.config4_set_args(rank + j * world, scale)
+        k, c = ctx.synth_set(a["seed"], a["first"], a["count"], a["key_bits"], mul=a["mul"], add=a["add"], mod=a["mod"])
+        sets.append((k, c))
+        sums = add_sums(sums, ctx.checksum_counts(k, c))
+        total += k.n
+    lk, lc = ctx.empty(total, np.uint64), ctx.empty(total, np.uint64)
+
+    def step():
+        k, c, _ = ctx.merge_n(sets, out=(lk, lc))
+        kt, ct, n = ex.ops.to_tensors(k, c)
+        return ex.merge_sets(kt, ct, n)
+
+    for _ in range(1):
+        step()
+    ex.comm.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    ctx.sync()
+    ex.comm.barrier()
+    dt = (time.perf_counter() - t0) / steps
+    dt = ex.comm.all_reduce([int(dt * 1e9)], "max")[0] / 1e9
+    ok = ex.verify_global(res["k"], res["c"], sums)
+    tot_all = ex.comm.all_reduce([total])[0]
+    owned = ex.comm.all_gather_object(res["k"].n)
+    return {"workload": "zot merge of %d sets x %d k-mers over %d GPUs (8 sets per GPU; BASELINE config 4 at 8 GPUs), owner = %s, transport = %s"
+                        % (8 * world, sets[0][0].n, world, ex.owner, ex.comm.name),
+            "value": tot_all / dt / 1e9, "unit": "G (k-mer,count) pairs/s", "ms_per_step": dt * 1e3, "pairs_in": tot_all,
+            "unique_out": res["n_global"], "owned_per_rank": owned, "balance_max_over_mean": max(owned) / (sum(owned) / float(world)),
+            "scaling": "weak", "verified": bool(ok), "verified_by": "checksum of checksums all-reduced over the ranks"}
+
+
+def extra_dist_multi(ctx, ex, steps, scale, world, rank):
+    """`zot dist` on BASELINE config 3 sharded over the GPUs (strong scaling: the two 100 M-k-mer sets are fixed): every rank
+    holds the rank-th contiguous piece of each sorted set, one exchange by owner, zk_split, all-reduce of (a, b, c)."""
+    import torch
+    from zotmer_amd import synth
+    c3 = synth.CONFIG3
+    n = int(c3["n"] * scale)
+    ka, _ = ctx.synth_set(c3["seed"], 0, n, c3["key_bits"], counts=False)
+    kb, _ = ctx.synth_set(c3["seed"], n // 2, n, c3["key_bits"], counts=False)
+    want = ctx.split(ka, kb)
+
+    def piece(k):
+        lo, hi = k.n * rank // world, k.n * (rank + 1) // world
+        t = torch.empty(max(hi - lo, 1), dtype=torch.int64, device="cuda")
+        if hi > lo:
+            ctx._check(ctx.lib.zk_copy(ctx.h, t.data_ptr(), k.ptr + 8 * lo, 8 * (hi - lo)))
+        ctx.sync()
+        return t, hi - lo
+
+    (xt, nx), (yt, ny) = piece(ka), piece(kb)
+    na, nb = ka.n, kb.n
+    del ka, kb
+    ex.dist_pair(xt, nx, yt, ny)
+    ex.comm.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        abc, sizes = ex.dist_pair(xt, nx, yt, ny)
+    ctx.sync()
+    ex.comm.barrier()
+    dt = (time.perf_counter() - t0) / steps
+    dt = ex.comm.all_reduce([int(dt * 1e9)], "max")[0] / 1e9
+    return {"workload": "zot dist on BASELINE config 3 (%d and %d k-mers) sharded over %d GPUs, owner = %s, transport = %s"
+                        % (na, nb, world, ex.owner, ex.comm.name),
+            "value": (na + nb) / dt / 1e9, "unit": "Gk-mers/s", "ms_per_step": dt * 1e3, "abc": list(abc), "scaling": "strong",
+            "verified": bool(tuple(abc) == tuple(want) and tuple(sizes) == (na, nb)),
+            "verified_by": "(a, b, c) equals the single-GPU zk_split of the whole sets"}
 
 
 def main():
@@ -87,13 +362,17 @@ def main():
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: config 2 = 50 M)")
     ap.add_argument("--both", action="store_true", help="sort both strands literally instead of canonical + mirror")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify", action="store_true", help="check the order-free checksums of the result against the stream")
+    ap.add_argument("--no-verify", action="store_true", help="skip the checksum verification of the timed result")
+    ap.add_argument("--verify", action="store_true", help="(default; kept for round-1 command lines)")
+    ap.add_argument("--no-extras", action="store_true", help="headline only")
+    ap.add_argument("--extras-scale", type=float, default=1.0, help="shrink the extra workloads (tests)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or os.environ.get("ZOT_FORCE_EXCHANGE") == "1":
+    force_exchange = os.environ.get("ZOT_FORCE_EXCHANGE") == "1"      # rehearse the N > 1 path with one rank
+    if world > 1 or force_exchange:
         # torch bundles its own HIP runtime: let it load first so that libzotk.so binds to the same
         # copy (same SONAME) instead of dragging a second runtime into the process
         import torch  # noqa: F401
@@ -103,20 +382,22 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     import __graft_entry__ as ge
-    if rank == 0:
-        ge.build()
-    from zotmer_amd import native, synth
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
 
     dist = None
-    force_exchange = os.environ.get("ZOT_FORCE_EXCHANGE") == "1"      # rehearse the N > 1 path with one rank
     if world > 1 or force_exchange:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    # one rank builds (normally a no-op: the library travels prebuilt), the others wait for it before they dlopen
+    if rank == 0:
+        ge.build()
+    if dist is not None and world > 1:
+        dist.barrier()
+    from zotmer_amd import native, synth
 
     cfg = dict(synth.CONFIGS["config2"])
     if a.reads:
@@ -133,23 +414,31 @@ def main():
     # distinct k-mers: 2 strands x (genome + ~21 novel windows per substitution); leave headroom
     est_unique = int(2 * (min(cfg["genome"], R * L) + R * L * cfg["sub"] * 22) * 1.25) + (1 << 20)
     cap = min(est_unique, 2 * n_bytes)
-    par = None
+    par, comm_note = None, None
     if dist is not None:
-        # the exchange goes through torch.distributed, so the table lives in torch tensors that the
-        # library writes through their data_ptr() (uint64 carried as int64, uint32 as int32)
+        # the exchange moves torch-owned tensors that the library writes through their data_ptr()
+        # (uint64 carried as int64, uint32 as int32)
         import torch
         from zotmer_amd import parallel
         kt = torch.empty(cap, dtype=torch.int64, device="cuda")
         ct = torch.empty(cap, dtype=torch.int32, device="cuda")
         out_k = native.DeviceArray.borrow(ctx, kt.data_ptr(), np.uint64, cap, keep=kt)
         out_c = native.DeviceArray.borrow(ctx, ct.data_ptr(), np.uint32, cap, keep=ct)
-        par = parallel.RangeExchange(ctx, dist, K)
+        try:
+            comm = parallel.make_comm(ctx, dist)
+        except Exception as e:      # recorded in the JSON line, never silent
+            comm_note = "zk_comm init failed (%s); torch.distributed transport used" % e
+            sys.stderr.write(comm_note + "\n")
+            comm = parallel.TorchComm(dist)
+        par = parallel.Exchange(ctx, dist, K, owner=os.environ.get("ZOT_OWNER", "range"), comm=comm)
     else:
         out_k, out_c = ctx.empty(cap, np.uint64), ctx.empty(cap, np.uint32)
 
     def step():
         k, c, st = ctx.kmerize(stream, K, flags, out=(out_k, out_c))
         if par is not None:
+            if par.owner == "range":
+                par.balanced_cuts([(kt, k.n)])
             k, c = par.exchange_and_merge(kt, ct, k.n)
         h = ctx.hist(c)
         return k, c, st, h
@@ -173,25 +462,50 @@ def main():
     prof = ctx.profile_read()
     ctx.profile(False)
 
+    owned = None
     if dist is not None:
         import torch
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([st.n_instances], dtype=torch.int64, device="cuda")
-        dist.all_reduce(tot)
-        total_instances = int(tot.item())
+        total_instances = par.comm.all_reduce([st.n_instances])[0]
+        owned = par.comm.all_gather_object(k.n)
     else:
         total_instances = st.n_instances
 
     verify = None
-    if a.verify:
+    if not a.no_verify:
         want = ctx.stream_checksum(stream, K)
         if par is None:
-            got = ctx.checksum(k, c)
-            verify = bool(got == want)
+            verify = bool(ctx.checksum(k, c) == want)
         else:
-            verify = par.verify_global(k, c, want)
+            verify = bool(par.verify_global(k, c, want))
+
+    extras = {}
+    if not a.no_extras:
+        sc = a.extras_scale
+        if par is None:
+            del k, c
+            for name, fn in (("config3_dist", lambda: extra_config3(ctx, 5, sc)),
+                             ("config4_merge_share", lambda: extra_config4_share(ctx, 3, sc)),
+                             ("config2_e2e_h2d", lambda: extra_e2e_h2d(ctx, stream, K, 2, out_k, out_c))):
+                try:
+                    extras[name] = fn()
+                except Exception as e:      # an extra never takes the headline down; the failure is in the line
+                    extras[name] = {"error": repr(e)}
+            del stream, out_k, out_c
+            stream = out_k = out_c = None
+            try:
+                extras["config5_share_k31"] = extra_config5_share(ctx, sc, synth, seed)
+            except Exception as e:
+                extras["config5_share_k31"] = {"error": repr(e)}
+        else:
+            for name, fn in (("merge_multi_gpu", lambda: extra_merge_multi(ctx, par, 3, sc, par.world, par.rank)),
+                             ("dist_multi_gpu", lambda: extra_dist_multi(ctx, par, 5, sc, par.world, par.rank))):
+                try:
+                    extras[name] = fn()
+                except Exception as e:
+                    extras[name] = {"error": repr(e)}
 
     if rank == 0:
         ms = dt / a.steps * 1e3
@@ -199,6 +513,7 @@ def main():
         pk = prof.get("pass_keys", dict(launches=0, ms=0.0, bytes=0))
         ach = (pk["bytes"] / 1e9) / (pk["ms"] / 1e3) if pk["ms"] else 0.0
         mb = model_bytes(n_bytes, st.n_instances, st.n_unique, K)
+        traffic = measured_traffic("pass_pipe_kernel<zk::Cfg<512, 16, 9, 1, 4, 32, true>, 0>", st.n_windows)
         out = {
             "metric": "Gk-mers/sec kmerize k=25 on synthetic 150bp FASTQ; achieved HBM GB/s fraction",
             "value": value, "unit": "Gk-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -209,12 +524,14 @@ def main():
                                    % (K, R, L),
                        "reads_per_gpu": R, "read_len": L, "K": K, "genome": cfg["genome"], "seed": seed,
                        "strategy": "both-strands" if a.both else "canonical+mirror",
-                       "parallelism": "1 gpu" if world == 1 else "reads sharded over %d gpus + value-range all-to-all" % world},
+                       "parallelism": "1 gpu" if world == 1 else "reads sharded over %d gpus + %s-owner all-to-all (%s)"
+                                      % (world, par.owner, par.comm.name)},
             "roofline": {"bound": "hbm", "kernel": "pass_pipe_kernel<array,keys> (one LSD radix pass of 64-bit keys, 16 B/key, persistent two-stage pipeline)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("pass_pipe_kernel<zk::Cfg<512, 16, 9, 1, 4, 32, true>, 0>", st.n_windows),
-                         "traffic_note": "HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE, KiB) of this "
-                                         "command, profiles/r01_config2_pipeline/pmc_traffic.json; null if the workload differs",
+                         "traffic": traffic["bytes"] if traffic else None,
+                         "traffic_note": ("HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) of this command and these kernel sources, "
+                                          + traffic["profile"]) if traffic else
+                                         "null: no committed PMC profile matches the current kernel sources and workload (tools/collect_traffic.py)",
                          "launches": pk["launches"],
                          "avg_launch_ms": pk["ms"] / pk["launches"] if pk["launches"] else None},
             "pipeline": {"windows_per_s": value * 1e9 / 2, "instances_per_step": st.n_instances, "unique": st.n_unique,
@@ -224,9 +541,14 @@ def main():
                          "kernels": {n: dict(launches=v["launches"], ms_per_step=v["ms"] / a.steps,
                                              GBps=(v["bytes"] / 1e9) / (v["ms"] / 1e3) if v["ms"] else None)
                                      for n, v in prof.items()}},
+            "verified_checksums": verify,
+            "extra": extras,
         }
-        if verify is not None:
-            out["verified_checksums"] = verify
+        if owned is not None:
+            out["owned_per_rank"] = owned
+            out["balance_max_over_mean"] = max(owned) / (sum(owned) / float(len(owned)))
+        if comm_note:
+            out["comm_note"] = comm_note
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, seed)
         elif not a.no_cpu_baseline:
@@ -236,6 +558,8 @@ def main():
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
     if dist is not None:
+        if par is not None and hasattr(par.comm, "close"):
+            par.comm.close()
         dist.destroy_process_group()
     ctx.close()
 

@@ -52,12 +52,18 @@ int zk_set_stream(zk_ctx* ctx, void* hip_stream);          /* borrow a hipStream
 void* zk_get_stream(zk_ctx* ctx);
 int zk_sync(zk_ctx* ctx);
 int zk_reserve(zk_ctx* ctx, uint64_t workspace_bytes);     /* grow the internal workspace now */
+int zk_release_workspace(zk_ctx* ctx);                      /* give the internal workspace back (it regrows on demand) */
 int zk_mem_info(zk_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 int zk_alloc(zk_ctx* ctx, uint64_t bytes, void** d_ptr);
 int zk_free(zk_ctx* ctx, void* d_ptr);
 int zk_upload(zk_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 int zk_download(zk_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
 int zk_copy(zk_ctx* ctx, void* d_dst, const void* d_src, uint64_t bytes);   /* device to device, async */
+/* page-locked host memory: transfers from / to it run at PCIe rate and asynchronously (the ingest path reads files
+ * straight into it); zk_upload_async queues the copy on the ctx's stream and returns */
+int zk_host_alloc(zk_ctx* ctx, uint64_t bytes, void** ptr);
+int zk_host_free(zk_ctx* ctx, void* ptr);
+int zk_upload_async(zk_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 
 /* Tuning knobs (performance only; results never depend on them). */
 #define ZK_TUNE_SORT_VARIANT 1   /* radix-sort geometry index for key arrays, see radix_sort.hip */

@@ -5,7 +5,8 @@ the gfx950 corrections of MI355X_MICROARCH.md (HBM section): the counters are in
 reports half of the bytes of a wide coalesced read stream and is doubled; WRITE_SIZE is exact.
 
 usage: collect_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [keys per array pass]"""
-import collections, csv, json, sys
+import collections, csv, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def per_kernel(path):
     agg = collections.defaultdict(list)
@@ -21,6 +22,9 @@ for name in f:
         out[name] = dict(launches=len(f[name]), fetch_size_kib=fk, write_size_kib=wk,
                          traffic_bytes_per_launch=(2 * fk + wk) * 1024,
                          n_keys=(int(sys.argv[4]) if len(sys.argv) > 4 and "pass_pipe_kernel" in name and name.rstrip().endswith(", 0>(zk::SortArgs, unsigned int)") else None))
+import bench     # the hash of the kernel sources the profile was taken from: bench.py quotes a row only while it matches
+out["_kernel_source_sha256"] = bench.kernel_source_hash()
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k, v in out.items():
-    print("%-100s %3d launches  %.2f GB/launch" % (k[:100], v["launches"], v["traffic_bytes_per_launch"] / 1e9))
+    if isinstance(v, dict):
+        print("%-100s %3d launches  %.2f GB/launch" % (k[:100], v["launches"], v["traffic_bytes_per_launch"] / 1e9))

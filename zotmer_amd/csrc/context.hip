@@ -271,6 +271,17 @@ int zk_reserve(zk_ctx* c, uint64_t workspace_bytes) {
     return ZK_OK;
 }
 
+int zk_release_workspace(zk_ctx* c) {
+    if (!c) return ZK_EINVAL;
+    enter(c);
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->arena) { ZK_HIP(c, hipFree(c->arena)); c->arena = nullptr; c->arena_size = 0; c->arena_off = 0; }
+    if (c->aux) { ZK_HIP(c, hipFree(c->aux)); c->aux = nullptr; c->aux_size = 0; }
+    if (c->status) { ZK_HIP(c, hipFree(c->status)); c->status = nullptr; c->status_words = 0; c->epoch = 0; }
+    if (c->part16) { ZK_HIP(c, hipFree(c->part16)); c->part16 = nullptr; c->part16_words = 0; }
+    return ZK_OK;
+}
+
 int zk_mem_info(zk_ctx* c, uint64_t* free_bytes, uint64_t* total_bytes) {
     if (!c) return ZK_EINVAL;
     enter(c);
@@ -347,6 +358,30 @@ int zk_free(zk_ctx* c, void* dptr) {
     if (!c) return ZK_EINVAL;
     enter(c);
     if (dptr) { ZK_HIP(c, hipStreamSynchronize(c->stream)); ZK_HIP(c, hipFree(dptr)); }
+    return ZK_OK;
+}
+
+int zk_host_alloc(zk_ctx* c, uint64_t bytes, void** ptr) {
+    if (!c || !ptr) return ZK_EINVAL;
+    enter(c);
+    *ptr = nullptr;
+    hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 256, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(c, ZK_ENOMEM, "hipHostMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+    return ZK_OK;
+}
+
+int zk_host_free(zk_ctx* c, void* ptr) {
+    if (!c) return ZK_EINVAL;
+    enter(c);
+    if (ptr) { ZK_HIP(c, hipStreamSynchronize(c->stream)); ZK_HIP(c, hipHostFree(ptr)); }
+    return ZK_OK;
+}
+
+int zk_upload_async(zk_ctx* c, void* dst_dev, const void* src_host, uint64_t bytes) {
+    if (!c) return ZK_EINVAL;
+    enter(c);
+    if (bytes == 0) return ZK_OK;
+    ZK_HIP(c, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
     return ZK_OK;
 }
 

@@ -48,12 +48,16 @@ SIGNATURES = {
     "zk_get_stream": (_vp, [_vp]),
     "zk_sync": (_i, [_vp]),
     "zk_reserve": (_i, [_vp, _u64]),
+    "zk_release_workspace": (_i, [_vp]),
     "zk_mem_info": (_i, [_vp, _pu64, _pu64]),
     "zk_alloc": (_i, [_vp, _u64, C.POINTER(_vp)]),
     "zk_free": (_i, [_vp, _vp]),
     "zk_upload": (_i, [_vp, _vp, _vp, _u64]),
     "zk_download": (_i, [_vp, _vp, _vp, _u64]),
     "zk_copy": (_i, [_vp, _vp, _vp, _u64]),
+    "zk_host_alloc": (_i, [_vp, _u64, C.POINTER(_vp)]),
+    "zk_host_free": (_i, [_vp, _vp]),
+    "zk_upload_async": (_i, [_vp, _vp, _vp, _u64]),
     "zk_tune": (_i, [_vp, _i, _i]),
     "zk_debug_buffer": (_i, [_vp, _vp]),
     "zk_profile": (_i, [_vp, _i]),
@@ -190,6 +194,9 @@ class Context:
         self._check(self.lib.zk_mem_info(self.h, C.byref(f), C.byref(t)))
         return f.value, t.value
 
+    def release_workspace(self):
+        self._check(self.lib.zk_release_workspace(self.h))
+
     def reserve(self, nbytes):
         self._check(self.lib.zk_reserve(self.h, int(nbytes)))
 
@@ -208,6 +215,33 @@ class Context:
         if a.size:
             self._check(self.lib.zk_upload(self.h, d.ptr, a.ctypes.data, a.nbytes))
         return d
+
+    def pinned(self, nbytes):
+        """A page-locked uint8 host buffer as a numpy array (freed with the returned object)."""
+        p = C.c_void_p(0)
+        self._check(self.lib.zk_host_alloc(self.h, int(nbytes), C.byref(p)))
+        ctx = self
+
+        class _Pinned:
+            def __init__(s):
+                s.ptr, s.n = p.value, int(nbytes)
+                s.array = np.ctypeslib.as_array((C.c_uint8 * max(s.n, 1)).from_address(s.ptr))[:s.n]
+
+            def free(s):
+                if s.ptr and ctx.h:
+                    s.array = None
+                    ctx.lib.zk_host_free(ctx.h, s.ptr)
+                s.ptr = None
+
+            def __del__(s):
+                try:
+                    s.free()
+                except Exception:
+                    pass
+        return _Pinned()
+
+    def upload_async(self, dst, src_ptr, nbytes):
+        self._check(self.lib.zk_upload_async(self.h, dst.ptr, src_ptr, int(nbytes)))
 
     def upload_stream(self, data):
         """bytes / uint8 array -> device base stream (zk_alloc memory is 256-byte aligned)."""
