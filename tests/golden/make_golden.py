@@ -157,7 +157,7 @@ def build_derived():
     files = [WORK + "/zotmer/library/%s.py" % m for m in
              ("basics", "bits", "misc", "codec64", "files", "file", "kmers", "reads", "dist", "exceptions", "timer", "stats")]
     files += [WORK + "/zotmer/library/container/%s.py" % m for m in ("__init__", "casket", "std", "vectors")]
-    files += [WORK + "/zotmer/commands/%s.py" % m for m in ("kmerize", "merge", "dist", "trim", "jaccard", "project", "sample")]
+    files += [WORK + "/zotmer/commands/%s.py" % m for m in ("kmerize", "merge", "dist", "trim", "jaccard", "project", "sample", "hist", "dump", "info")]
     subprocess.check_call([sys.executable, "-W", "ignore", "-m", "lib2to3", "-w", "-n"] + files,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
@@ -369,6 +369,28 @@ def commands():
     save_case("f3_sample_defaults", *load_set(W + "smp2.k25"), extra=dict(input="g4_part0", S=0, P=0.01,
               note="docopt gives False (not None) for an absent -D, so commands/sample.py:51 always takes the deterministic branch"))
     print("f3:", {k: v["stdout"][:70] for k, v in f3.items()})
+
+    # f4: the inspection commands' stdout (hist / dump / info) on two of the sets above.  The reference prints the path it
+    # was given; it is replaced by the case name.  NB `zot info` prints Python reprs of the JSON-loaded metadata: under the
+    # reference's Python 2 strings carry a u'' prefix and dict order is arbitrary; this is the Python 3 rendering of the
+    # same code (sorted by key at the top level, insertion = file order inside `hist`).
+    f4 = {}
+    for case, path in (("g9_edge_fastq", W + "g9.k25"), ("g4_merge3", W + "m3.k25")):
+        for cmd in ("hist", "dump", "info"):
+            o, e = run(cmd, {"<input>": path if cmd == "dump" else [path]})
+            o = o.replace(path, case)
+            if len(o) > (1 << 16):      # a long dump is kept as its digest, line count and first lines
+                f4["%s_%s" % (cmd, case)] = dict(input=case, sha256=hashlib.sha256(o.encode()).hexdigest(), lines=o.count("\n"),
+                                                 head="".join(o.splitlines(True)[:20]), stderr=e)
+            else:
+                f4["%s_%s" % (cmd, case)] = dict(input=case, stdout=o, stderr=e)
+    with open(os.path.join(HERE, "f4_inspect.json"), "w") as f:
+        json.dump(f4, f, indent=1, sort_keys=True)
+    print("f4:", {k: len(v.get("stdout", v.get("head"))) for k, v in f4.items()})
+
+    # -C together with -D: the reference's `if d is not None: ... elif B is not None:` (kmerize.py:494-520) ignores the baits
+    kz(25, W + "g10cd.k25", [W + "g3.fastq"], **{"-C": W + "bait.fa", "-D": "0.8", "-S": "3"})
+    save_case("g10_kmerize_capture_and_D", *load_set(W + "g10cd.k25"), extra=dict(K=25, synth=g3, bait_fasta=bait, D=0.8, S=3))
 
     # config 1 at full size (10 000 x 150 bp genome-sampled): digests only
     c = synth.CONFIGS["config1"]

@@ -93,6 +93,12 @@ def test_kmerize_subsample_and_capture(tmp_path):
     check_file(tmp_path / "c.k25", "g10_kmerize_capture")
     zot("kmerize", "-C", bait, "-m", "1", 25, tmp_path / "c2.k25", fq)
     check_file(tmp_path / "c2.k25", "g10_kmerize_capture")
+    # -C together with -D: the reference's `if d is not None ... elif B is not None` lets -D win and ignores the baits
+    zot("kmerize", "-C", bait, "-D", "0.8", "-S", "3", 25, tmp_path / "cd.k25", fq)
+    check_file(tmp_path / "cd.k25", "g10_kmerize_capture_and_D")
+    gcd = G.load_case("g10_kmerize_capture_and_D")
+    gd = G.load_case("g10_kmerize_D0.8_S3")
+    assert np.array_equal(gcd[1], gd[1]) and np.array_equal(gcd[2], gd[2])      # (the two reference outputs are the same set)
 
 
 def test_kmerize_k31_overflow_raises(tmp_path):
@@ -167,15 +173,33 @@ def test_trim_files(tmp_path):
 
 
 def test_info_hist_dump(tmp_path):
-    src = make_set(tmp_path, "g9_edge_fastq")
-    out, _ = zot("info", src)
-    assert "K 25" in out.split("\n")
-    out, _ = zot("hist", src)
-    info, km, ct, _, _ = G.load_case("g9_edge_fastq")
-    assert out == "".join("%s\t%d\t%d\n" % (src, int(f), c) for f, c in sorted((int(f), c) for f, c in info["meta"]["hist"].items()))
-    out, _ = zot("dump", src)
-    from oracle import zkoracle as zo
-    assert out == "".join("%s\t%d\n" % (zo.render(25, int(k)), int(c)) for k, c in zip(km, ct))
+    """stdout of the inspection commands against what the reference's own hist.py / dump.py / info.py printed
+    (tests/golden/f4_inspect.json, captured by make_golden.py; the path the reference printed is the case name there)."""
+    import ast
+    import hashlib
+    g = G.load_json("f4_inspect")
+    for case in ("g9_edge_fastq", "g4_merge3"):
+        src = make_set(tmp_path, case)
+        out, _ = zot("hist", src)
+        assert out.replace(str(src), case) == g["hist_" + case]["stdout"]
+        out, _ = zot("dump", src)
+        want = g["dump_" + case]
+        if "stdout" in want:
+            assert out == want["stdout"]
+        else:
+            assert hashlib.sha256(out.encode()).hexdigest() == want["sha256"] and out.count("\n") == want["lines"]
+            assert out.startswith(want["head"])
+        # info prints Python reprs of the metadata; the order INSIDE the hist dict is the file's JSON order, which not even the
+        # reference reproduces from run to run, so that one value is compared as a dict
+        out, _ = zot("info", src)
+        got = dict(l.split(" ", 1) for l in out.strip().split("\n"))
+        ref = dict(l.split(" ", 1) for l in g["info_" + case]["stdout"].strip().split("\n"))
+        assert sorted(got) == sorted(ref) and list(got) == sorted(got)
+        for k in ref:
+            if k == "hist":
+                assert ast.literal_eval(got[k]) == ast.literal_eval(ref[k])
+            else:
+                assert got[k] == ref[k], k
     _, rc = zot("nosuchcommand")
     assert rc == 1
 

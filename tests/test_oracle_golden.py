@@ -129,6 +129,9 @@ def test_kmerize_subsample_and_capture():
     b = np.unique(np.concatenate([zo.kmers_list(25, s, True) for s in bait]))
     r = zo.kmerize(25, reads, mode=2, baits=b)
     _check_set(info, km, ct, r)
+    # -C with -D: the reference takes the -D branch and never looks at the baits (kmerize.py:494-520)
+    info, km, ct, _, _ = G.load_case("g10_kmerize_capture_and_D")
+    _check_set(info, km, ct, zo.kmerize(25, reads, mode=1, p=info["D"], seed=info["S"]))
 
 
 def test_k31_delta_overflow():
