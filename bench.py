@@ -366,12 +366,16 @@ def main():
     ap.add_argument("--verify", action="store_true", help="(default; kept for round-1 command lines)")
     ap.add_argument("--no-extras", action="store_true", help="headline only")
     ap.add_argument("--extras-scale", type=float, default=1.0, help="shrink the extra workloads (tests)")
+    ap.add_argument("--only-extra", default="", help="run just this extra block (development): skips the headline")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     force_exchange = os.environ.get("ZOT_FORCE_EXCHANGE") == "1"      # rehearse the N > 1 path with one rank
+    if force_exchange and world == 1:
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533")):
+            os.environ.setdefault(k, v)
     if world > 1 or force_exchange:
         # torch bundles its own HIP runtime: let it load first so that libzotk.so binds to the same
         # copy (same SONAME) instead of dragging a second runtime into the process
@@ -407,6 +411,15 @@ def main():
     flags = native.KMERIZE_BOTH if a.both else native.KMERIZE_CANONICAL
 
     ctx = native.Context(local)
+    if a.only_extra:
+        fn = {"config3_dist": lambda: extra_config3(ctx, 5, a.extras_scale),
+              "config4_merge_share": lambda: extra_config4_share(ctx, 3, a.extras_scale),
+              "config5_share_k31": lambda: extra_config5_share(ctx, a.extras_scale, synth, seed)}[a.only_extra]
+        r = fn()
+        os.dup2(real_stdout, 1)
+        print(json.dumps({a.only_extra: r}), flush=True)
+        ctx.close()
+        return
     n_bytes = R * (L + 1)
     stream = ctx.synth_reads(seed, rank * R, R, L, genome=cfg["genome"], sub_thr=synth.frac32(cfg["sub"]),
                              n_thr=synth.frac32(cfg["n"]))

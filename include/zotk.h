@@ -271,6 +271,27 @@ int zk_parse_fasta(const char* buf, uint64_t len, int final, uint64_t state[4], 
  * d_stream may not alias d_text; both 16-byte aligned. */
 int zk_fastq_mask(zk_ctx* ctx, const uint8_t* d_text, uint64_t n, uint32_t line_phase, uint8_t* d_stream, uint64_t* n_newlines);
 
+/* ---- ingest: file bytes <-> device memory (next-row f2 of SURVEY.md section 8) --------------------------------------
+ * Replaces file.readFastq / openFile + `gunzip -c` (library/file.py:38-52,79-123) feeding reads.next (library/reads.py:86-98):
+ * the text is parsed on the device (zk_fastq_mask), the host only moves bytes.  A zk_source reads a file -- plain, or gzip
+ * (detected by its magic; multi-member files included) -- AHEAD of the device: a background thread fills page-locked
+ * buffers (parallel pread, or zlib inflate) and queues them as asynchronous H2D copies on a copy stream of its own, so
+ * reading / inflating, PCIe and the kernels working on the previous batch overlap.  zk_source_start names the device
+ * buffer of the next batch and returns at once; zk_source_finish waits and says how many bytes arrived (fewer than
+ * asked only at the end of the input).  Batches are cut at line ends with zk_last_newline (position just after the last
+ * newline of d_text[0, n), 0 if none) and the tail is carried to the front of the next buffer by the caller (zk_copy). */
+typedef struct zk_source zk_source;
+zk_source* zk_source_open(zk_ctx* ctx, const char* path, int threads);      /* NULL on failure: zk_last_error(ctx) */
+int zk_source_is_gzip(zk_source* src);
+int zk_source_start(zk_source* src, uint8_t* d_dst, uint64_t cap);
+int zk_source_finish(zk_source* src, uint64_t* n_bytes, int* eof);
+void zk_source_close(zk_source* src);
+int zk_last_newline(zk_ctx* ctx, const uint8_t* d_text, uint64_t n, uint64_t* cut);
+/* a member of a k-mer set between device memory and a region of an open file (files.writeWords / readWords,
+ * library/files.py:54-83): D2H / H2D through the page-locked ring, pwrite / pread in `threads` parallel slices */
+int zk_device_to_file(zk_ctx* ctx, const void* d_src, uint64_t bytes, int fd, uint64_t file_offset, int threads);
+int zk_file_to_device(zk_ctx* ctx, int fd, uint64_t file_offset, uint64_t bytes, void* d_dst, int threads);
+
 /* ---- synthetic input (bench / tests) ------------------------------------- */
 
 /* Reads first .. first+count-1 of the counter-based generator (zotmer_amd/synth.py) as a base

@@ -72,15 +72,32 @@ def main(argv):
             baits = ctx.upload(np.empty(0, np.uint64))
 
     table = engine.KmerTable(ctx, K, subsample=subsample, baits=baits)
-    batch = engine.batch_bytes_for(ctx, (int(opts["-m"]) << 20) if opts["-m"] is not None else None)
+    requested = (int(opts["-m"]) << 20) if opts["-m"] is not None else None
     n_reads = 0
     n_batch = 0                                     # multi-GPU: rank r counts batches r, r + world, ... (reads are independent)
     timing = os.environ.get("ZOT_TIMING") == "1"
     t_parse = t_gpu = 0.0
     t0 = time.perf_counter()
     for path in inputs:                             # files are simply processed in sequence (reads.py:66-93)
-        if seqio.is_fasta(path):
+        native_fastq = (not seqio.is_fasta(path)) and path != "-" and not path.endswith(".bz2") and os.path.isfile(path)
+        if native_fastq:
+            # FASTQ, plain or gzip: the file is read ahead of the device by a native reader and parsed ON the device
+            # (library/engine.py count_fastq_file, csrc/ingest.hip); the host never looks at the text
+            size = os.path.getsize(path) * (4 if path.endswith(".gz") else 1)
+            batch = engine.batch_bytes_for(ctx, requested, input_bytes=size)
+            base = n_batch
+
+            def take(i, base=base):
+                return (base + i) % world == rank
+            t1 = time.perf_counter()
+            recs = engine.count_fastq_file(ctx, table, path, batch, take=take if world > 1 else None)
+            n_batch += -(-size // batch)
+            n_reads += recs
+            t_gpu += time.perf_counter() - t1
+            t0 = time.perf_counter()
+        elif seqio.is_fasta(path):
             # FASTA records span lines and must be joined: host chunk parser, then upload
+            batch = engine.batch_bytes_for(ctx, requested)
             for stream, recs in seqio.base_stream_batches([path], batch_bytes=batch):
                 t1 = time.perf_counter()
                 t_parse += t1 - t0
@@ -91,8 +108,8 @@ def main(argv):
                 t_gpu += t0 - t1
                 n_reads += recs                     # kmerize.py:527: every record counts
         else:
-            # FASTQ: the text goes to the GPU as it is and is parsed there (zk_fastq_mask); the masked
-            # stream is about twice as long as the bases alone, so batches are half as many reads
+            # stdin / .bz2: Python reads (and decompresses) the text, the device still parses it (zk_fastq_mask)
+            batch = engine.batch_bytes_for(ctx, requested)
             for text, phase, recs in seqio.fastq_text_batches(path, batch_bytes=batch):
                 t1 = time.perf_counter()
                 t_parse += t1 - t0

@@ -222,6 +222,7 @@ void zk_destroy(zk_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)zk_comm_destroy(c);
+    ring_destroy(c);
     for (auto& r : c->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     if (c->arena) (void)hipFree(c->arena);
     if (c->aux) (void)hipFree(c->aux);

@@ -54,6 +54,8 @@ struct zk_ctx {
     int comm_world = 1, comm_rank = 0;
     uint64_t comm_chunk_bytes = 0;      // bytes per message and round of zk_all_to_all_v (0 = 256 MiB; zk_tune, tests)
 
+    void* ring = nullptr;               // page-locked staging ring + copy stream of the file <-> device paths (ingest.hip)
+
     // optional per-launch timing with HIP events on this stream (zk_profile_*)
     struct ProfRec { int tag; uint64_t bytes; hipEvent_t a, b; };
     bool profile = false;
@@ -136,6 +138,8 @@ int fastq_mask(zk_ctx* c, const u8* d_text, uint64_t n, uint32_t line_phase, u8*
 int codec_encode(zk_ctx* c, const u64* d_vals, uint64_t n, int delta, u64* d_words, uint64_t cap, uint64_t* n_words);
 int scan64_inclusive(zk_ctx* c, u64* d_v, uint64_t n);   // in place, asynchronous
 int add_u64(zk_ctx* c, u64* d_v, uint64_t n, u64 x);     // v[i] += x, asynchronous
+// ingest.hip
+void ring_destroy(zk_ctx* c);
 // partition.hip
 int hash_partition(zk_ctx* c, const u64* keys, const void* cnts, int count_bits, uint64_t n, int world, u64 seed, u64* ok, void* oc,
                    uint64_t* offsets);

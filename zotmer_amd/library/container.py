@@ -83,6 +83,26 @@ class Container:
         f.write(mv)
         self.toc.setdefault(name, []).append([off, len(mv)])
 
+    def add_device(self, name, ctx, arr):
+        """Append a member straight from device memory (D2H through page-locked buffers, parallel pwrite: csrc/ingest.hip)."""
+        if self.mode != "w":
+            raise IOError("container opened read-only")
+        if self._streaming:
+            raise IOError("cannot add to the container while a streamed member is open")
+        f = self._f
+        f.seek(0, os.SEEK_END)
+        off = f.tell()
+        f.flush()
+        if arr.nbytes:
+            ctx.device_to_file(arr, f.fileno(), off)
+            f.seek(0, os.SEEK_END)
+        self.toc.setdefault(name, []).append([off, arr.nbytes])
+
+    def read_device(self, name, ctx, dtype):
+        """The latest version of a member as a device array of `dtype` (parallel pread, H2D through page-locked buffers)."""
+        off, length = self.toc[name][-1]
+        return ctx.file_to_device(self._f.fileno(), off, length, dtype)
+
     def add_stream(self, name):
         """A write()-able object; its bytes become member `name` when it is closed."""
         if self.mode != "w":

@@ -6,6 +6,8 @@ sorted table (zk_union_sum); nothing is spilled to disk -- the final arrays do n
 the batches are cut (verified against the reference's -m 1 run, tests/golden).
 """
 import os
+import sys
+import time
 
 import numpy as np
 
@@ -39,30 +41,99 @@ def distributed():
 
 def close():
     global _ctx
+    for sl in _slabs.values():
+        sl.release()
+    _slabs.clear()
     if _ctx is not None:
         _ctx.close()
         _ctx = None
 
 
-def batch_bytes_for(ctx, requested=None):
-    """How much base stream to count per device batch.  zk_kmerize needs about 16 B of sort buffer per stream byte, up
-    to 24 B per distinct canonical k-mer for the mirror step and 12 B per output entry; 80 B per byte is a safe
-    envelope.  Half of the free memory is left for the table that grows while batches are counted (KmerTable checks
-    again before every batch)."""
+def batch_bytes_for(ctx, requested=None, input_bytes=None):
+    """How much text / base stream to count per device batch.  zk_kmerize needs about 16 B of sort buffer per stream byte,
+    up to 24 B per distinct canonical k-mer for the mirror step, and the table slab holds 12 B per entry; 80 B per byte is
+    a safe envelope, and half of the free memory is left for the table that grows while batches are counted.  Without -m
+    the batch follows the input size (an eighth of it, between 64 MiB and 2 GiB): device memory costs ~25 ms per GB to
+    allocate on this stack, so small inputs should not reserve large workspaces, and large inputs want few merges."""
     free, _ = ctx.mem_info()
     b = max(1 << 20, int(free * 0.5) // 80)
     if requested:
         b = min(b, int(requested))
+    elif input_bytes is not None:
+        b = min(b, max(64 << 20, min(int(input_bytes) // 8, 2 << 30)))
     return min(b, 6 << 30)
 
 
-class KmerTable:
-    """Sorted distinct k-mers + counts on the device, grown batch by batch.
+_TIMING = os.environ.get("ZOT_TIMING") == "2"
 
-    Every batch is counted into its own sorted table; tables are union-summed pairwise like a binary counter (two
-    tables of the same level make one of the next), so n batches cost O(n log n) table traffic instead of the
-    O(n^2) of re-merging one resident table per batch, and nothing is copied per batch but the batch's own result.
-    The final arrays do not depend on where the batches are cut (the reference's -m 1 run, tests/golden)."""
+
+class _Phase:
+    """ZOT_TIMING=2: wall time of the phases of a batch on stderr (development aid)"""
+
+    def __init__(self, ctx, what):
+        self.ctx, self.what = ctx, what
+
+    def __enter__(self):
+        if _TIMING:
+            self.ctx.sync()
+            self.t = time.perf_counter()
+
+    def __exit__(self, *a):
+        if _TIMING:
+            self.ctx.sync()
+            sys.stderr.write("  [engine] %-28s %8.1f ms\n" % (self.what, (time.perf_counter() - self.t) * 1e3))
+
+
+class Slab:
+    """The table memory: keys u64[E] and counts u32[E] with the same entry offsets, allocated once per context and kept
+    between commands (hipMalloc costs ~25 ms per GB here: a table must not be reallocated per batch).  Grows by allocating
+    a larger pair and copying the live prefix."""
+
+    def __init__(self, ctx):
+        self.ctx, self.k, self.c, self.E = ctx, None, None, 0
+
+    def ensure(self, need, live):
+        if need <= self.E:
+            return
+        ctx = self.ctx
+        want = max(int(need), int(self.E * 1.5))
+        with _Phase(ctx, "grow table slab to %d" % want):
+            try:
+                nk, nc = ctx.empty(want, np.uint64), ctx.empty(want, np.uint32)
+            except native.ZotkError:
+                nk = nc = None
+                want = int(need)                  # the geometric step does not fit: take exactly what is needed
+                nk, nc = ctx.empty(want, np.uint64), ctx.empty(want, np.uint32)
+            if live:
+                ctx._check(ctx.lib.zk_copy(ctx.h, nk.ptr, self.k.ptr, 8 * live))
+                ctx._check(ctx.lib.zk_copy(ctx.h, nc.ptr, self.c.ptr, 4 * live))
+                ctx.sync()
+            self.k, self.c, self.E = nk, nc, want
+
+    def release(self):
+        self.k = self.c = None
+        self.E = 0
+
+
+_slabs = {}
+
+
+def slab_for(ctx):
+    s = _slabs.get(id(ctx))
+    if s is None or s.ctx is not ctx:
+        s = _slabs[id(ctx)] = Slab(ctx)
+    return s
+
+
+class KmerTable:
+    """Sorted distinct k-mers + counts on the device, grown batch by batch -- the role of the reference's KmerAccumulator2 +
+    spill files + mergeNinto (zotmer/commands/kmerize.py:236-304,370-437,528-553).
+
+    Every batch is sorted and counted (zk_kmerize) straight into the top of the table slab; tables sit on a stack and are
+    union-summed pairwise like a binary counter (two tables of the same level make one of the next; the result is written
+    above the stack and moved down over its inputs), so n batches cost O(n log n) table traffic, nothing is allocated
+    per batch, and peak memory is the final table plus one merge output.  The final arrays do not depend on where the
+    batches are cut (the reference's -m 1 run, tests/golden)."""
 
     def __init__(self, ctx, K, subsample=None, baits=None):
         self.ctx, self.K = ctx, K
@@ -73,75 +144,80 @@ class KmerTable:
             self.p, self.seed = subsample
             baits = None              # `if d is not None: ... elif B is not None:` (kmerize.py:494-520): -D wins over -C
         self.baits = baits            # DeviceArray of sorted both-strand bait k-mers, or None
-        self.parts = []               # [(level, kmers, counts)], levels strictly decreasing towards the end
+        self.slab = slab_for(ctx)
+        self.stack = []               # [(offset, n, level)] bottom to top, contiguous from offset 0
+        self.top = 0
+        self.ratio = None             # largest entries-per-stream-byte seen so far (sizes the next batch's output)
         self.acgt = [0, 0, 0, 0]
         self.instances = 0
-        self._out = None              # the batch output buffers, reused while they are big enough
 
+    # ---- input forms --------------------------------------------------------------------------------------
     def add_fastq_text(self, text, line_phase):
-        """Count one batch of raw FASTQ text (whole lines): parsed on the device (zk_fastq_mask)."""
-        self._make_room(2 * len(text))
+        """Count one batch of raw FASTQ text (whole lines, host bytes): parsed on the device (zk_fastq_mask)."""
         d = self.ctx.upload_stream(text)
         if d.n == 0:
             return
         stream, _ = self.ctx.fastq_mask(d, line_phase)
         del d
-        self.add_device_stream(stream)
+        self.add_device_stream(stream, bound=stream.n)
 
     def add_stream(self, stream_host):
         """Count one batch (uint8 base stream on the host) into the table."""
-        self._make_room(len(stream_host))
         self.add_device_stream(self.ctx.upload_stream(stream_host))
 
-    def _make_room(self, n_bytes):
-        """Before a batch: if the free memory no longer covers the batch's envelope, fold the waiting tables into one
-        (frees their slack and the merge outputs' upper-bound padding); fail clearly if that is not enough."""
-        need = 80 * int(n_bytes)
-        free, _ = self.ctx.mem_info()
-        if free >= need:
-            return
-        self._out = None
-        self._fold(0)
-        free, _ = self.ctx.mem_info()
-        if free < need:
-            raise native.ZotkError(native.ZK_ENOMEM, "a batch of %d bytes needs about %d bytes of device memory, %d are free "
-                                   "(table so far: %d entries); use a smaller -m" % (n_bytes, need, free, sum(p[1].n for p in self.parts)))
-
-    def add_device_stream(self, d):
-        ctx = self.ctx
+    def add_device_stream(self, d, bound=None):
+        """d: base stream on the device.  bound: an upper bound on the entries it can produce (default 2 per byte: one
+        window per byte, both strands; FASTQ text gives less than 1 per byte: sequence lines are under half of it)."""
+        ctx, slab = self.ctx, self.slab
         if d.n == 0:
             return
-        cap = 2 * d.n
-        if self._out is None or self._out[0].n < cap:
-            self._out = None
-            self._out = (ctx.empty(cap, np.uint64), ctx.empty(cap, np.uint32))
+        bound = int(bound) if bound else 2 * d.n
+        est = bound if self.ratio is None else min(bound, int(d.n * self.ratio * 1.2) + 65536)
+        acgt = None
         if self.baits is not None:
             # acgt is taken over every read, before the capture filter (kmerize.py:492-493 vs :510-520)
             acgt = ctx.stream_acgt(d, self.K)
             d, _, _ = ctx.capture_filter(d, self.K, self.baits)
-            k, c, st = ctx.kmerize(d, self.K, self.flags, self.p, self.seed, out=self._out)
-        else:
-            k, c, st = ctx.kmerize(d, self.K, self.flags, self.p, self.seed, out=self._out)
+        while True:
+            slab.ensure(self.top + est, self.top)
+            out = (slab.k.view(est, self.top), slab.c.view(est, self.top))
+            try:
+                with _Phase(ctx, "zk_kmerize"):
+                    k, c, st = ctx.kmerize(d, self.K, self.flags, self.p, self.seed, out=out)
+                break
+            except native.ZotkError as e:
+                if e.code != native.ZK_ENOSPC or est >= bound:
+                    raise
+                est = min(bound, 2 * est)          # the estimate from earlier batches was too small: once more with room
+        if acgt is None:
             acgt = list(st.acgt)
         for b in range(4):
             self.acgt[b] += acgt[b]
         self.instances += sum(acgt)
+        self.ratio = max(self.ratio or 0.0, k.n / float(d.n))
         if k.n == 0:
             return
-        self.parts.append((0, ctx.copy_of(k), ctx.copy_of(c)))     # exact-size copies: the batch buffers are reused
-        while len(self.parts) >= 2 and self.parts[-1][0] == self.parts[-2][0]:
-            lv, bk, bc = self.parts.pop()
-            _, ak, ac = self.parts.pop()
-            nk, nc = ctx.union_sum(ak, ac, bk, bc)
-            self.parts.append((lv + 1, nk, nc))
+        self.stack.append((self.top, k.n, 0))
+        self.top += k.n
+        while len(self.stack) >= 2 and self.stack[-1][2] == self.stack[-2][2]:
+            self._merge_top()
 
-    def _fold(self, keep):
-        """union-sum the waiting tables down to one"""
-        ctx = self.ctx
-        if len(self.parts) > 1:
-            k, c, _ = ctx.merge_n([(p[1], p[2]) for p in self.parts])
-            top = max(p[0] for p in self.parts) + 1
-            self.parts = [(top, ctx.copy_of(k), ctx.copy_of(c))]
+    def _merge_top(self):
+        """union-sum the two tables on top of the stack into one (written above them, then moved down over them)"""
+        ctx, slab = self.ctx, self.slab
+        ob, nb, lb = self.stack.pop()
+        oa, na, la = self.stack.pop()
+        assert oa + na == ob and ob + nb == self.top
+        slab.ensure(self.top + na + nb, self.top)
+        with _Phase(ctx, "union_sum %d + %d" % (na, nb)):
+            out = (slab.k.view(na + nb, self.top), slab.c.view(na + nb, self.top))
+            mk, mc = ctx.union_sum(slab.k.view(na, oa), slab.c.view(na, oa), slab.k.view(nb, ob), slab.c.view(nb, ob), out=out)
+            n = mk.n                 # n <= na + nb = top - oa: source and destination of the move never overlap
+            ctx._check(ctx.lib.zk_copy(ctx.h, slab.k.ptr + 8 * oa, mk.ptr, 8 * n))
+            ctx._check(ctx.lib.zk_copy(ctx.h, slab.c.ptr + 4 * oa, mc.ptr, 4 * n))
+            ctx.sync()
+        self.stack.append((oa, n, max(la, lb) + 1))
+        self.top = oa + n
 
     def result(self):
         """(kmers u64[], counts u32[], hist {count: n}) on the host."""
@@ -149,10 +225,76 @@ class KmerTable:
         return k.to_host(), c.to_host(), h
 
     def device_result(self):
-        """(kmers, counts) as device arrays + hist, for the device codec."""
-        if not self.parts:
-            return self.ctx.empty(0, np.uint64).view(0), self.ctx.empty(0, np.uint32).view(0), {}
-        self._out = None
-        self._fold(0)
-        _, k, c = self.parts[0]
-        return k, c, self.ctx.hist(c)
+        """(kmers, counts) as device arrays (views of the table slab, valid until the slab is used again) + hist."""
+        if not self.stack:
+            e = self.ctx.empty(0, np.uint64)
+            return e.view(0), self.ctx.empty(0, np.uint32).view(0), {}
+        while len(self.stack) > 1:
+            self._merge_top()
+        off, n, _ = self.stack[0]
+        k, c = self.slab.k.view(n, off), self.slab.c.view(n, off)
+        with _Phase(self.ctx, "hist"):
+            h = self.ctx.hist(c)
+        return k, c, h
+
+
+# ---- FASTQ files straight to the device (csrc/ingest.hip) -------------------------------------------------------
+
+def count_fastq_file(ctx, table, path, batch_bytes, take=None):
+    """file.readFastq (zotmer/library/file.py:38-52) for a whole file without the host parsing a byte: a zk_source reads the
+    file (plain or gzip) ahead of the device into one of two device buffers while the other is being counted; batches are
+    cut at line ends on the device, the bytes after the cut are carried to the front of the next buffer; zk_fastq_mask turns
+    the text into a base stream and counts the lines.  take(batch index) -> bool selects the batches this process counts
+    (multi-GPU: reads are sharded by batch).  Returns the number of records (kmerize.py:527 counts every record)."""
+    B = int(batch_bytes)
+    lines = 0
+    with ctx.source_open(path) as src:
+        bufs = [ctx.empty(B + 64, np.uint8), ctx.empty(B + 64, np.uint8)]
+        masked = ctx.empty(B + 64, np.uint8)
+        cur, carry, index = 0, 0, 0
+        src.start(bufs[0], 0, B)
+        while True:
+            with _Phase(ctx, "wait for the reader"):
+                got, eof = src.finish()
+            buf, n = bufs[cur], carry + got
+            if eof:
+                cut = n
+            else:
+                cut = ctx.last_newline(buf, n)
+                if cut == 0:
+                    raise IOError("%s: a line longer than the batch size (%d bytes); use a larger -m" % (path, B))
+                tail = n - cut
+                nxt = bufs[1 - cur]
+                if tail:
+                    ctx._check(ctx.lib.zk_copy(ctx.h, nxt.ptr, buf.ptr + cut, tail))
+                    ctx.sync()
+                src.start(nxt, tail, B - tail)          # the next batch streams in while this one is counted
+                carry = tail
+            if eof and cut and buf.view(1, cut - 1).to_host()[0] != 10:
+                ctx._check(ctx.lib.zk_upload(ctx.h, buf.ptr + cut, b"\n", 1))      # the last line counts without a terminator
+                cut += 1
+            if cut:
+                stream, nl = ctx.fastq_mask(buf.view(cut), lines % 4, out=masked.view(cut))
+                if eof and (lines + nl) % 4:
+                    # an incomplete final record: file.readFastq drops it (file.py:51-52) -- find where its lines start and
+                    # mask again without them (malformed input only; the tail is scanned on the host)
+                    extra = (lines + nl) % 4
+                    m = min(cut, 1 << 22)
+                    t = buf.view(m, cut - m).to_host().tobytes()
+                    pos = len(t)
+                    for _ in range(extra):
+                        pos = t.rfind(b"\n", 0, pos - 1) + 1 if pos > 0 else 0
+                    if pos == 0 and m < cut:
+                        raise IOError("%s: the incomplete final record is longer than 4 MiB" % path)
+                    cut = cut - m + pos
+                    nl -= extra
+                    if cut:
+                        stream, _ = ctx.fastq_mask(buf.view(cut), lines % 4, out=masked.view(cut))
+                if cut and (take is None or take(index)):
+                    table.add_device_stream(stream, bound=cut)
+                lines += nl
+                index += 1
+            if eof:
+                break
+            cur = 1 - cur
+    return lines // 4

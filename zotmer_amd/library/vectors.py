@@ -118,23 +118,31 @@ def device_encode_counts(ctx, counts_dev):
 
 
 def device_write_kmers_and_counts(ctx, z, kmers_dev, counts_dev):
-    z.add("kmers", device_encode_kmers(ctx, kmers_dev))
-    z.add("counts", device_encode_counts(ctx, counts_dev))
+    """files.writeKmersAndCounts2 (files.py:209-217) from device arrays: delta + codec64 on the device (K12), the word streams
+    go from device memory to the file without a host copy of our own (Container.add_device)."""
+    if kmers_dev.n == 0:
+        z.add("kmers", b"")
+        z.add("counts", b"")
+        return
+    words = _check_codec(ctx.codec_encode, kmers_dev, True)
+    z.add_device("kmers", ctx, words)
+    del words
+    c64 = ctx.widen(counts_dev) if counts_dev.dtype.itemsize == 4 else counts_dev
+    words = _check_codec(ctx.codec_encode, c64, False)
+    z.add_device("counts", ctx, words)
 
 
 def device_read_kmers(ctx, z):
     """'kmers' member -> uint64 k-mers on the device"""
-    data = z.read("kmers")
-    if not data:
+    if z.member_size("kmers") == 0:
         return ctx.empty(0, np.uint64)
-    return _check_codec(ctx.codec_decode, ctx.upload(np.frombuffer(data, dtype="<u8")), True)
+    return _check_codec(ctx.codec_decode, z.read_device("kmers", ctx, "<u8"), True)
 
 
 def device_read_kmers_and_counts(ctx, z):
     """(k-mers, counts) of a set as uint64 device arrays"""
     k = device_read_kmers(ctx, z)
-    data = z.read("counts")
-    c = _check_codec(ctx.codec_decode, ctx.upload(np.frombuffer(data, dtype="<u8")), False) if data else ctx.empty(0, np.uint64)
+    c = _check_codec(ctx.codec_decode, z.read_device("counts", ctx, "<u8"), False) if z.member_size("counts") else ctx.empty(0, np.uint64)
     if k.n != c.n:
         raise CodecError("k-mer and count vectors differ in length (%d vs %d)" % (k.n, c.n))
     return k, c

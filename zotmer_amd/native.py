@@ -87,6 +87,14 @@ SIGNATURES = {
     "zk_codec64_encode_dev": (_i, [_vp, _vp, _u64, _i, _vp, _u64, _pu64]),
     "zk_codec64_decode_dev": (_i, [_vp, _vp, _u64, _i, _vp, _u64, _pu64]),
     "zk_fastq_mask": (_i, [_vp, _vp, _u64, _u32, _vp, _pu64]),
+    "zk_source_open": (_vp, [_vp, C.c_char_p, _i]),
+    "zk_source_is_gzip": (_i, [_vp]),
+    "zk_source_start": (_i, [_vp, _vp, _u64]),
+    "zk_source_finish": (_i, [_vp, _pu64, C.POINTER(_i)]),
+    "zk_source_close": (None, [_vp]),
+    "zk_last_newline": (_i, [_vp, _vp, _u64, _pu64]),
+    "zk_device_to_file": (_i, [_vp, _vp, _u64, _i, _u64, _i]),
+    "zk_file_to_device": (_i, [_vp, _i, _u64, _u64, _vp, _i]),
     "zk_undelta": (_i, [_vp, _vp, _u64, _u64]),
     "zk_add_u64": (_i, [_vp, _vp, _u64, _u64]),
     "zk_parse_fastq": (_i, [_vp, _u64, _i, _pu64, _vp, _u64, _pu64, _pu64]),
@@ -160,6 +168,38 @@ class DeviceArray:
             self.free()
         except Exception:
             pass
+
+
+class Source:
+    """zk_source: a file (plain or gzip) read ahead of the device through page-locked buffers and a copy stream."""
+
+    def __init__(self, ctx, path, threads):
+        self.ctx = ctx
+        self.h = ctx.lib.zk_source_open(ctx.h, os.fsencode(path), int(threads))
+        if not self.h:
+            raise IOError(ctx.lib.zk_last_error(ctx.h).decode(errors="replace"))
+        self.gzip = bool(ctx.lib.zk_source_is_gzip(self.h))
+
+    def start(self, dst, offset, cap):
+        """begin reading up to cap bytes into dst[offset:] (a uint8 DeviceArray); returns at once"""
+        self.ctx._check(self.ctx.lib.zk_source_start(self.h, dst.ptr + int(offset), int(cap)))
+
+    def finish(self):
+        """wait for the request -> (bytes that arrived, end of input reached)"""
+        n, eof = C.c_uint64(0), C.c_int(0)
+        self.ctx._check(self.ctx.lib.zk_source_finish(self.h, C.byref(n), C.byref(eof)))
+        return n.value, bool(eof.value)
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.zk_source_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 class Context:
@@ -242,6 +282,27 @@ class Context:
 
     def upload_async(self, dst, src_ptr, nbytes):
         self._check(self.lib.zk_upload_async(self.h, dst.ptr, src_ptr, int(nbytes)))
+
+    # ---- ingest: files <-> device memory (csrc/ingest.hip) -------------------------------------------------
+    IO_THREADS = max(1, min(8, (os.cpu_count() or 2) - 1))
+
+    def source_open(self, path, threads=None):
+        return Source(self, path, threads or self.IO_THREADS)
+
+    def last_newline(self, text, n):
+        """position just after the last newline of the first n bytes of a device text buffer (0: none)"""
+        cut = C.c_uint64(0)
+        self._check(self.lib.zk_last_newline(self.h, text.ptr, int(n), C.byref(cut)))
+        return cut.value
+
+    def device_to_file(self, arr, fileno, offset, threads=None):
+        self._check(self.lib.zk_device_to_file(self.h, arr.ptr, arr.nbytes, int(fileno), int(offset), threads or self.IO_THREADS))
+
+    def file_to_device(self, fileno, offset, nbytes, dtype=np.uint8, threads=None):
+        dt = np.dtype(dtype)
+        out = self.empty(nbytes // dt.itemsize, dt)
+        self._check(self.lib.zk_file_to_device(self.h, int(fileno), int(offset), int(nbytes), out.ptr, threads or self.IO_THREADS))
+        return out
 
     def upload_stream(self, data):
         """bytes / uint8 array -> device base stream (zk_alloc memory is 256-byte aligned)."""
@@ -355,11 +416,15 @@ class Context:
         self._check(self.lib.zk_widen_counts(self.h, counts32.ptr, out.ptr, counts32.n))
         return out
 
-    def union_sum(self, xk, xc, yk, yc, want_acgt=False):
+    def union_sum(self, xk, xc, yk, yc, want_acgt=False, out=None):
         bits = xc.dtype.itemsize * 8
         assert yc.dtype == xc.dtype
-        cap = xk.n + yk.n
-        ok, oc = self.empty(cap, np.uint64), self.empty(cap, xc.dtype)
+        if out is None:
+            cap = xk.n + yk.n
+            ok, oc = self.empty(cap, np.uint64), self.empty(cap, xc.dtype)
+        else:
+            ok, oc = out
+            cap = min(ok.n, oc.n)
         n = C.c_uint64(0)
         acgt = (C.c_uint64 * 4)()
         self._check(self.lib.zk_union_sum(self.h, xk.ptr, xc.ptr, xk.n, yk.ptr, yc.ptr, yk.n, ok.ptr, oc.ptr, bits, cap,
@@ -426,9 +491,9 @@ class Context:
         self._check(self.lib.zk_add_u64(self.h, vals.ptr, vals.n, int(x) & 0xFFFFFFFFFFFFFFFF))
         return vals
 
-    def fastq_mask(self, text, line_phase=0):
+    def fastq_mask(self, text, line_phase=0, out=None):
         """FASTQ text on the device -> (base stream of the same length, number of newlines)."""
-        out = self.empty(text.n, np.uint8)
+        out = out if out is not None else self.empty(text.n, np.uint8)
         n = C.c_uint64(0)
         self._check(self.lib.zk_fastq_mask(self.h, text.ptr, text.n, int(line_phase) & 3, out.ptr, C.byref(n)))
         return out, n.value
