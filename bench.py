@@ -213,44 +213,58 @@ def extra_config4_share(ctx, steps, scale):
 
 def extra_config5_share(ctx, scale, synth, seed, batches=4):
     """One GPU's share of BASELINE config 5 (K = 31, 300 M reads / 8 = 37.5 M x 150 bp from a 3.1 Gbp genome): at ~1.8x coverage
-    nearly every k-mer is distinct (about 6.8 G entries = 81 GB for one GPU), so the share is counted the way `zot kmerize`
-    does it -- library/engine.py KmerTable: batches, each sorted and counted on its own, tables union-summed pairwise.  Timed:
-    everything from the resident base stream of a batch to the final table + hist (allocation churn included); the synthetic
-    streams themselves are generated outside the timed region."""
+    nearly every k-mer is distinct (about 5.6 G entries = 68 GB for one GPU), so the share is counted the way `zot kmerize`
+    does it -- library/engine.py KmerTable: batches, each sorted and counted straight into the table slab, tables
+    union-summed pairwise.  Timed: from the resident base stream of each batch to the final table + hist.  The procedure
+    runs twice: `cold_ms` includes growing the table slab and the sort workspace (hipMalloc costs ~25 ms per GB on this
+    stack and is paid once per process), `value` is the second run with the memory in place.  The synthetic streams are
+    generated outside the timed region."""
     from zotmer_amd.library import engine
     c5 = synth.CONFIGS["config5"]
     R5, L, K = int(c5["reads"] // 8 * scale), c5["L"], c5["K"]
     per = -(-R5 // batches)
     ctx.release_workspace()                      # config 2 left a 120 GB sort arena behind
-    table = engine.KmerTable(ctx, K)
-    want, t_total, inst = (0, 0, 0), 0.0, 0
-    for b in range(batches):
-        n = min(per, R5 - b * per)
-        if n <= 0:
-            break
-        d = ctx.synth_reads(seed, b * per, n, L, genome=c5["genome"], sub_thr=synth.frac32(c5["sub"]), n_thr=synth.frac32(c5["n"]))
-        want = add_sums(want, ctx.stream_checksum(d, K))
-        ctx.sync()
+    runs = []
+    for attempt in range(2):
+        table = engine.KmerTable(ctx, K)
+        table.expect(R5 * (L + 1))
+        want, t_total = (0, 0, 0), 0.0
+        for b in range(batches):
+            n = min(per, R5 - b * per)
+            if n <= 0:
+                break
+            d = ctx.synth_reads(seed, b * per, n, L, genome=c5["genome"], sub_thr=synth.frac32(c5["sub"]), n_thr=synth.frac32(c5["n"]))
+            if attempt == 0:
+                want = add_sums(want, ctx.stream_checksum(d, K))
+            ctx.sync()
+            t0 = time.perf_counter()
+            table.add_device_stream(d)
+            ctx.sync()
+            t_total += time.perf_counter() - t0
+            del d
         t0 = time.perf_counter()
-        table.add_device_stream(d)
+        k, c, h = table.device_result()
         ctx.sync()
         t_total += time.perf_counter() - t0
-        del d
-    t0 = time.perf_counter()
-    k, c, h = table.device_result()
-    ctx.sync()
-    t_total += time.perf_counter() - t0
+        runs.append(t_total)
+        if attempt == 0:
+            want0 = want
     inst = table.instances
-    ok = ctx.checksum(k, c) == want and inst == want[0]
+    ok = ctx.checksum(k, c) == want0 and inst == want0[0]
     n_unique = k.n
     mb = model_bytes(R5 * (L + 1), inst, n_unique, K)
+    slab_bytes = 12 * (table.slab.E + table.scratch.E)
     del k, c, table
+    engine.release_table_memory(ctx)
     ctx.release_workspace()
+    t = runs[1]
     return {"workload": "one GPU's share of BASELINE config 5: zot kmerize k=%d, %d x %d bp reads (300 M / 8), genome %d, in %d batches "
-                        "(library/engine.py KmerTable: per-batch sort + count, pairwise union-sum), hist included" % (K, R5, L, c5["genome"], batches),
-            "value": inst / t_total / 1e9, "unit": "Gk-mers/s", "ms_total": t_total * 1e3, "instances": inst, "unique": n_unique,
+                        "(library/engine.py KmerTable: per-batch sort + count into the table slab, pairwise union-sum), hist included"
+                        % (K, R5, L, c5["genome"], batches),
+            "value": inst / t / 1e9, "unit": "Gk-mers/s", "ms_total": t * 1e3, "cold_ms": runs[0] * 1e3, "table_slab_bytes": slab_bytes,
+            "instances": inst, "unique": n_unique,
             "verified": bool(ok), "verified_by": "order-free checksums of the final table == the sums taken from the base streams of all batches",
-            "roofline": {"bound": "hbm", "model_bytes": mb, "model_frac_of_peak": mb / t_total / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
+            "roofline": {"bound": "hbm", "model_bytes": mb, "model_frac_of_peak": mb / t / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
 
 
 def extra_e2e_h2d(ctx, stream, K, steps, out_k, out_c):

@@ -21,7 +21,7 @@ K = 25
 def ctx():
     c = native.Context(0)
     yield c
-    engine._slabs.clear()
+    engine.release_table_memory(c)
     c.close()
 
 
@@ -120,7 +120,7 @@ def test_device_file_round_trip(ctx, tmp_path, n):
 def test_table_slab_survives_growth_and_estimates(ctx):
     """batches of very different yield: the per-byte estimate from a poor batch is too small for a rich one (ZK_ENOSPC retry),
     and the slab grows while tables are live"""
-    engine._slabs.clear()
+    engine.release_table_memory(ctx)
     rich = _reads(3000, first=5000)
     poor = ["N" * 150] * 2000 + _reads(20)
     t = engine.KmerTable(ctx, K)

@@ -72,6 +72,12 @@ def main(argv):
             baits = ctx.upload(np.empty(0, np.uint64))
 
     table = engine.KmerTable(ctx, K, subsample=subsample, baits=baits)
+    try:                                            # how much text is coming: lets the table memory be sized in one step
+        total_in = sum(os.path.getsize(p) * (4 if p.endswith((".gz", ".bz2")) else 1) for p in inputs if os.path.isfile(p))
+        if world == 1 and total_in:
+            table.expect(total_in)
+    except OSError:
+        pass
     requested = (int(opts["-m"]) << 20) if opts["-m"] is not None else None
     n_reads = 0
     n_batch = 0                                     # multi-GPU: rank r counts batches r, r + world, ... (reads are independent)

@@ -41,8 +41,9 @@ def distributed():
 
 def close():
     global _ctx
-    for sl in _slabs.values():
-        sl.release()
+    for pair in list(_slabs.values()):
+        for sl in pair:
+            sl.release()
     _slabs.clear()
     if _ctx is not None:
         _ctx.close()
@@ -85,25 +86,29 @@ class _Phase:
 
 
 class Slab:
-    """The table memory: keys u64[E] and counts u32[E] with the same entry offsets, allocated once per context and kept
-    between commands (hipMalloc costs ~25 ms per GB here: a table must not be reallocated per batch).  Grows by allocating
-    a larger pair and copying the live prefix."""
+    """A pair of device arrays, keys u64[E] and counts u32[E], addressed by the same entry offsets, allocated once per
+    context and kept between commands (hipMalloc costs ~25 ms per GB here: table memory must not be reallocated per batch).
+    ensure() grows it: with live entries a larger pair is allocated and the prefix copied; with none the old pair is freed
+    first, so the peak is the new size only."""
 
     def __init__(self, ctx):
         self.ctx, self.k, self.c, self.E = ctx, None, None, 0
 
-    def ensure(self, need, live):
+    def ensure(self, need, live=0, target=None):
+        """make room for `need` entries, preserving the first `live`; `target` (>= need) is the size to grow to if it fits"""
         if need <= self.E:
             return
         ctx = self.ctx
-        want = max(int(need), int(self.E * 1.5))
-        with _Phase(ctx, "grow table slab to %d" % want):
-            try:
-                nk, nc = ctx.empty(want, np.uint64), ctx.empty(want, np.uint32)
-            except native.ZotkError:
-                nk = nc = None
-                want = int(need)                  # the geometric step does not fit: take exactly what is needed
-                nk, nc = ctx.empty(want, np.uint64), ctx.empty(want, np.uint32)
+        want = max(int(need), int(target or 0), int(self.E * 1.5) if live else 0)
+        free, _ = ctx.mem_info()
+        room = free + (0 if live else 12 * self.E)
+        if 12 * want + (1 << 30) > room:                      # the comfortable size does not fit: take exactly what is needed
+            want = int(need)
+        with _Phase(ctx, "table memory -> %d entries" % want):
+            if not live:
+                self.k = self.c = None
+                self.E = 0
+            nk, nc = ctx.empty(want, np.uint64), ctx.empty(want, np.uint32)
             if live:
                 ctx._check(ctx.lib.zk_copy(ctx.h, nk.ptr, self.k.ptr, 8 * live))
                 ctx._check(ctx.lib.zk_copy(ctx.h, nc.ptr, self.c.ptr, 4 * live))
@@ -118,22 +123,30 @@ class Slab:
 _slabs = {}
 
 
-def slab_for(ctx):
+def slabs_for(ctx):
+    """(table slab, merge scratch) of a context"""
     s = _slabs.get(id(ctx))
-    if s is None or s.ctx is not ctx:
-        s = _slabs[id(ctx)] = Slab(ctx)
+    if s is None or s[0].ctx is not ctx:
+        s = _slabs[id(ctx)] = (Slab(ctx), Slab(ctx))
     return s
+
+
+def release_table_memory(ctx):
+    for sl in _slabs.pop(id(ctx), ()):
+        sl.release()
 
 
 class KmerTable:
     """Sorted distinct k-mers + counts on the device, grown batch by batch -- the role of the reference's KmerAccumulator2 +
     spill files + mergeNinto (zotmer/commands/kmerize.py:236-304,370-437,528-553).
 
-    Every batch is sorted and counted (zk_kmerize) straight into the top of the table slab; tables sit on a stack and are
-    union-summed pairwise like a binary counter (two tables of the same level make one of the next; the result is written
-    above the stack and moved down over its inputs), so n batches cost O(n log n) table traffic, nothing is allocated
-    per batch, and peak memory is the final table plus one merge output.  The final arrays do not depend on where the
-    batches are cut (the reference's -m 1 run, tests/golden)."""
+    Every batch is sorted and counted (zk_kmerize) straight into the top of the table slab; the tables sit on a stack and
+    are union-summed pairwise like a binary counter (two tables of the same level make one of the next): the union goes to
+    a scratch slab sized for exactly |A u B| (|A n B| is one cheap intersect pass) and is copied back over its inputs.  So
+    n batches cost O(n log n) table traffic, steady state allocates nothing, and peak memory is the live tables plus one
+    merge output.  The final arrays do not depend on where the batches are cut (the reference's -m 1 run, tests/golden)."""
+
+    EXACT_FROM = 1 << 25        # merges of at least this many entries size their output by an intersect pass first
 
     def __init__(self, ctx, K, subsample=None, baits=None):
         self.ctx, self.K = ctx, K
@@ -144,12 +157,28 @@ class KmerTable:
             self.p, self.seed = subsample
             baits = None              # `if d is not None: ... elif B is not None:` (kmerize.py:494-520): -D wins over -C
         self.baits = baits            # DeviceArray of sorted both-strand bait k-mers, or None
-        self.slab = slab_for(ctx)
+        self.slab, self.scratch = slabs_for(ctx)
         self.stack = []               # [(offset, n, level)] bottom to top, contiguous from offset 0
         self.top = 0
         self.ratio = None             # largest entries-per-stream-byte seen so far (sizes the next batch's output)
+        self.expected_bytes = None    # total stream bytes the caller expects to feed (sizes the slab in one step)
+        self.seen_bytes = 0
         self.acgt = [0, 0, 0, 0]
         self.instances = 0
+
+    def expect(self, total_stream_bytes):
+        """The caller knows how much input is coming: after the first batch the table slab is grown ONCE to the size that
+        much input can need at the yield seen so far, instead of geometrically."""
+        self.expected_bytes = int(total_stream_bytes)
+
+    def _slab_target(self, need):
+        if self.expected_bytes is None or self.ratio is None:
+            return None
+        rest = max(self.expected_bytes - self.seen_bytes, 0)
+        predicted = self.top + int(rest * self.ratio * 1.05) + 65536      # as if later batches shared nothing with earlier ones
+        # ... which overshoots on high-coverage data (most k-mers of a later batch are already in the table), and memory
+        # costs time to allocate: never more than double in one step
+        return max(need, min(predicted, 2 * max(self.slab.E, need)))
 
     # ---- input forms --------------------------------------------------------------------------------------
     def add_fastq_text(self, text, line_phase):
@@ -174,12 +203,13 @@ class KmerTable:
         bound = int(bound) if bound else 2 * d.n
         est = bound if self.ratio is None else min(bound, int(d.n * self.ratio * 1.2) + 65536)
         acgt = None
+        n_in = d.n
         if self.baits is not None:
             # acgt is taken over every read, before the capture filter (kmerize.py:492-493 vs :510-520)
             acgt = ctx.stream_acgt(d, self.K)
             d, _, _ = ctx.capture_filter(d, self.K, self.baits)
         while True:
-            slab.ensure(self.top + est, self.top)
+            slab.ensure(self.top + est, self.top, self._slab_target(self.top + est))
             out = (slab.k.view(est, self.top), slab.c.view(est, self.top))
             try:
                 with _Phase(ctx, "zk_kmerize"):
@@ -194,7 +224,8 @@ class KmerTable:
         for b in range(4):
             self.acgt[b] += acgt[b]
         self.instances += sum(acgt)
-        self.ratio = max(self.ratio or 0.0, k.n / float(d.n))
+        self.seen_bytes += n_in
+        self.ratio = max(self.ratio or 0.0, k.n / float(n_in))
         if k.n == 0:
             return
         self.stack.append((self.top, k.n, 0))
@@ -203,16 +234,21 @@ class KmerTable:
             self._merge_top()
 
     def _merge_top(self):
-        """union-sum the two tables on top of the stack into one (written above them, then moved down over them)"""
-        ctx, slab = self.ctx, self.slab
+        """union-sum the two tables on top of the stack into one: into the scratch slab, then back over the inputs"""
+        ctx, slab, scratch = self.ctx, self.slab, self.scratch
         ob, nb, lb = self.stack.pop()
         oa, na, la = self.stack.pop()
         assert oa + na == ob and ob + nb == self.top
-        slab.ensure(self.top + na + nb, self.top)
+        ak, ac = slab.k.view(na, oa), slab.c.view(na, oa)
+        bk, bc = slab.k.view(nb, ob), slab.c.view(nb, ob)
+        n_out = na + nb
+        if n_out >= self.EXACT_FROM:
+            with _Phase(ctx, "intersect (size the union)"):
+                n_out -= ctx.split(ak, bk)[0]
+        scratch.ensure(n_out)
         with _Phase(ctx, "union_sum %d + %d" % (na, nb)):
-            out = (slab.k.view(na + nb, self.top), slab.c.view(na + nb, self.top))
-            mk, mc = ctx.union_sum(slab.k.view(na, oa), slab.c.view(na, oa), slab.k.view(nb, ob), slab.c.view(nb, ob), out=out)
-            n = mk.n                 # n <= na + nb = top - oa: source and destination of the move never overlap
+            mk, mc = ctx.union_sum(ak, ac, bk, bc, out=(scratch.k.view(n_out), scratch.c.view(n_out)))
+            n = mk.n
             ctx._check(ctx.lib.zk_copy(ctx.h, slab.k.ptr + 8 * oa, mk.ptr, 8 * n))
             ctx._check(ctx.lib.zk_copy(ctx.h, slab.c.ptr + 4 * oa, mc.ptr, 4 * n))
             ctx.sync()
