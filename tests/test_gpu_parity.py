@@ -281,6 +281,33 @@ def test_kmerize_short_sort_paths_agree(ctx, K):
         ctx.tune(short_sort=0, side_div=8)
 
 
+@pytest.mark.parametrize("K", [9, 14, 25, 31, 32])
+def test_kmerize_early_collapse_paths_agree(ctx, K):
+    """zk_kmerize (canonical) counts runs after the passes over the low bits and finishes the sort on (k-mer, count) pairs when a
+    sample says the reads repeat their k-mers; otherwise the keys finish the sort.  Both ways, and with the collapse switched
+    off, the arrays must be the oracle's -- also when distinct k-mers share all their low bits, so that their copies interleave
+    and the final reduce has to add up split runs."""
+    rng = np.random.default_rng(100 + K)
+    deep = synth.read_strings(11, 0, 6000, 150, genome=12000, sub_thr=synth.frac32(0.004), n_thr=synth.frac32(0.001))   # ~60x: collapses
+    flat = synth.read_strings(12, 0, 3000, 150, genome=0)                                                              # no repeats: refused
+    # k-mers that differ only in their FIRST bases (high bits) and share every low bit, many copies each, interleaved
+    tail = "".join(rng.choice(list("ACGT"), size=40))
+    shared = [h + tail for h in ("A", "C", "G", "T", "AC", "GT", "TTA", "CAG")] * 400
+    rng.shuffle(shared)
+    for name, reads in (("deep", deep), ("flat", flat), ("shared_low_bits", shared + deep[:500]), ("mixed", deep[:2000] + flat[:2000] + shared)):
+        want = zo.kmerize(K, reads)
+        d = ctx.upload_stream(stream_of(reads))
+        try:
+            for on in (1, 0):
+                ctx.tune(early_collapse=on)
+                k, c, st = ctx.kmerize(d, K)
+                assert np.array_equal(k.to_host(), want["kmers"]), (name, on)
+                assert np.array_equal(c.to_host(), want["counts"]), (name, on)
+                assert list(st.acgt) == want["acgt"] and st.n_unique == len(want["kmers"])
+        finally:
+            ctx.tune(early_collapse=1)
+
+
 @pytest.mark.parametrize("case", ["u150", "u150_k13", "u100", "u40", "u255", "alt_149_151", "last_short", "n_at_separator", "one_read"])
 def test_kmerize_record_aligned_tiles_and_fallbacks(ctx, case):
     """Pass 0 lays its tiles along the records when every record has the same length (checked on the device); any other
@@ -349,6 +376,12 @@ def test_kmerize_large_properties(ctx):
     k2, c2, st2 = ctx.kmerize(d, K, native.KMERIZE_BOTH, cap=len(kh) + 16)
     assert np.array_equal(k2.to_host(), kh) and np.array_equal(c2.to_host(), ch)
     assert list(st2.acgt) == list(st.acgt)
+    ctx.tune(early_collapse=0)                   # the plain full-width sort of the canonical keys
+    try:
+        k4, c4, _ = ctx.kmerize(d, K, native.KMERIZE_CANONICAL, cap=len(kh) + 16)
+        assert np.array_equal(k4.to_host(), kh) and np.array_equal(c4.to_host(), ch)
+    finally:
+        ctx.tune(early_collapse=1)
     # the same reads through the oracle on a 20 000-read prefix
     pre = ctx.synth_reads(synth.DEFAULT_SEED, 0, 20000, L, genome=4_000_000, sub_thr=synth.frac32(0.005), n_thr=synth.frac32(0.0005))
     reads = pre.to_host().tobytes().decode().split("\n")[:-1]

@@ -17,6 +17,7 @@ struct zk_ctx {
     int sort_variant = 3;      // radix-sort geometry for key arrays (zk_tune); 3 = 512 threads x 16 keys, 9-bit digits
     int short_sort = 0;        // zk_kmerize: 1 = sort only the top ~log2(n)+3 bits and finish in the mirror stage (opt-in:
                                // pays off on uncorrelated reads only)
+    int early_collapse = 1;    // zk_kmerize (canonical): run-length count after the low-bit passes, finish the sort on pairs (pipeline.hip)
     int side_div = 8;          // ... side list capacity = n / side_div (tests shrink it to force the fallback)
     int pairs_variant = 2;     // ... for (key, u32) pairs
 
@@ -106,11 +107,12 @@ static inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; 
 int sort_workspace_bytes(uint64_t n, bool pairs, uint64_t* bytes);
 int sort_keys(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** result);
 int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, u64** rk, u32** rv);
+int sort_keys_upper(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, int lo_bit, u64** result);
 int sort_pairs_upper(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, int lo_bit, u64** rk, u32** rv);
 int sort_pairs_mirrored(zk_ctx* c, const u64* src_k, const u32* src_v, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int K,
                         u64** rk, u32** rv);
 // sort whose first pass generates the keys from a base stream (encode.hip + radix_sort.hip)
-struct StreamSrc { const u8* stream; uint64_t n_bytes; int K; int mode; int lo_bit; };   // mode: ZK_KEYS_*; sort bits [lo_bit, 2K)
+struct StreamSrc { const u8* stream; uint64_t n_bytes; int K; int mode; int lo_bit; int hi_bit = 0; };   // mode: ZK_KEYS_*; sort bits [lo_bit, hi_bit) (hi_bit 0 = 2K)
 int sort_rbits(zk_ctx* c);
 int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,
                 uint64_t acgt[4], u64** result);
@@ -128,6 +130,7 @@ int capture_filter(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, const u
                    uint64_t* n_reads, uint64_t* n_kept);
 int rle_prefix(zk_ctx* c, const u64* sorted, uint64_t n, int pshift, u64* uniq, u32* counts, uint64_t cap, uint64_t* n_main,
                u64* side_k, u32* side_c, uint64_t side_cap, uint64_t* n_side);
+int sample_heads(zk_ctx* c, const u64* keys, uint64_t n, uint64_t* sampled, uint64_t* heads);   // adjacent-distinct count of a prefix
 int reduce_by_key(zk_ctx* c, const u64* sorted, const u32* w, uint64_t n, u64* uniq, u32* sums, uint64_t cap, uint64_t* n_out);
 int rle(zk_ctx* c, const u64* sorted, uint64_t n, u64* uniq, u32* counts, uint64_t cap, uint64_t* n_unique);
 int count_hist(zk_ctx* c, const void* counts, int count_bits, uint64_t n, uint64_t* vals, uint64_t* freq,

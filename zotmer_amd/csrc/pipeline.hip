@@ -121,9 +121,26 @@ __global__ void side_expand_kernel(const u64* __restrict__ k, const u32* __restr
 static int ilog2_ceil(uint64_t x) { int b = 0; while ((1ull << b) < x && b < 63) b++; return b; }
 
 // The literal paths: every bit sorted, then RLE; canonical keys are mirrored afterwards.
+//
+// Early collapse (canonical mode).  Sequencing reads repeat every k-mer `coverage` times, and an LSD sort drags all those
+// copies through every pass.  But after the passes over the low b bits the copies of a k-mer are already NEIGHBOURS as soon
+// as 2^b is well above the number of keys (two distinct k-mers rarely share their low b bits), so the run-length count
+// can be taken THEN: the remaining passes move (k-mer, count) pairs -- one per distinct k-mer instead of one per copy --
+// and a final pass adds up the few k-mers whose copies were interleaved with another k-mer's (reduce_by_key).  Exact
+// for any input: collapsing adjacent equal keys and summing equal keys later never loses or invents a count; the data
+// only decides how much is saved.  Whether it pays is read off a sample of the partially sorted array (its head holds a
+// random subset of the k-mers with all their copies); with little duplication the keys finish the sort as before.
 static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bool both, u64* buf_a, u64* buf_b, uint64_t cap_keys,
                         u64* out_k, u32* out_c, uint64_t cap, zk_kmerize_stats* st, uint64_t* n_out) {
     StreamSrc src{stream, n_bytes, K, both ? ZK_KEYS_BOTH : ZK_KEYS_CANONICAL, 0};
+    // low bits to sort before looking for runs: 2^b >= 8 x keys, a whole number of passes, and at least one pass left over
+    int collapse_bit = 0;
+    if (!both && c->early_collapse) {
+        const int rb = sort_rbits(c);
+        const int b = rb * ((ilog2_ceil(n_bytes) + 3 + rb - 1) / rb);
+        if (b + rb / 2 < 2 * K) collapse_bit = b;
+    }
+    src.hi_bit = collapse_bit;
     uint64_t n = 0;
     u64* sorted = nullptr;
     ZK_TRY(sort_stream(c, src, buf_a, buf_b, cap_keys, &n, st->acgt, &sorted));
@@ -137,14 +154,50 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     u64* other = (sorted == buf_a) ? buf_b : buf_a;
     u32* cnt = (u32*)other;
     uint64_t uc = 0;
-    ZK_TRY(rle(c, sorted, n, sorted, cnt, n, &uc));     // in place: sorted[0..uc) = distinct canonical k-mers
+    bool in_aux = false;          // the counted list lives in the aux region (collapse path): both sort buffers are free
+    if (collapse_bit && n) {
+        uint64_t m = 0, heads = 0;
+        ZK_TRY(sample_heads(c, sorted, n, &m, &heads));
+        if ((double)heads <= 0.6 * (double)m) {
+            uint64_t u1 = 0;
+            ZK_TRY(rle(c, sorted, n, sorted, cnt, n, &u1));          // in place: runs of adjacent equal keys
+            const uint64_t a8 = (8 * u1 + 255) & ~255ull, a4 = (4 * u1 + 255) & ~255ull;
+            // the second key / count buffers of the pair passes sit behind the lists in the two sort buffers; should the
+            // sample have been too optimistic for that (it never is on reads), they go to the aux region instead
+            const bool fits = a8 + a4 + 512 <= 8 * cap_keys;
+            char* aux;
+            ZK_TRY(aux_require(c, (fits ? 1 : 2) * (a8 + a4), &aux));
+            u64* alt = fits ? (u64*)((char*)other + a4) : (u64*)(aux + a8 + a4);
+            u32* valt = fits ? (u32*)((char*)sorted + a8) : (u32*)(aux + 2 * a8 + a4);
+            u64* sk; u32* sv;
+            ZK_TRY(sort_pairs_upper(c, sorted, alt, cnt, valt, u1, 2 * K, collapse_bit, &sk, &sv));
+            ZK_TRY(reduce_by_key(c, sk, sv, u1, (u64*)aux, (u32*)(aux + a8), u1, &uc));
+            sorted = (u64*)aux; cnt = (u32*)(aux + a8);
+            in_aux = true;
+        } else {
+            u64* res = nullptr;
+            ZK_TRY(sort_keys_upper(c, sorted, other, n, 2 * K, collapse_bit, &res));
+            sorted = res;
+            other = (sorted == buf_a) ? buf_b : buf_a;
+            cnt = (u32*)other;
+            collapse_bit = 0;
+        }
+    }
+    if (!in_aux) ZK_TRY(rle(c, sorted, n, sorted, cnt, n, &uc));     // in place: sorted[0..uc) = distinct canonical k-mers
     st->n_canonical = uc;
     if (uc == 0) return ZK_OK;
     const uint64_t a8 = (8 * uc + 255) & ~255ull, a4 = (4 * uc + 255) & ~255ull;
-    char* aux;
-    ZK_TRY(aux_require(c, 2 * a8 + 2 * a4, &aux));
-    u64* rk = (u64*)aux; u64* rk2 = (u64*)(aux + a8);
-    u32* rv = (u32*)(aux + 2 * a8); u32* rv2 = (u32*)(aux + 2 * a8 + a4);
+    u64 *rk, *rk2; u32 *rv, *rv2;
+    if (in_aux) {
+        // both sort buffers are free: the mirror sort works there
+        rk = buf_a; rv = (u32*)((char*)buf_a + a8);
+        rk2 = buf_b; rv2 = (u32*)((char*)buf_b + a8);
+    } else {
+        char* aux;
+        ZK_TRY(aux_require(c, 2 * a8 + 2 * a4, &aux));
+        rk = (u64*)aux; rk2 = (u64*)(aux + a8);
+        rv = (u32*)(aux + 2 * a8); rv2 = (u32*)(aux + 2 * a8 + a4);
+    }
     u64* sk; u32* sv;
     if (2 * K >= MIRROR_GROUP_BITS + 8 && uc >= (1ull << 16)) {
         // The list (c, n) is sorted by c, so the k-mers that share their first 9 bases are contiguous -- and those are

@@ -1190,8 +1190,9 @@ struct Sorter {
         return ZK_OK;
     }
 
-    static int sort_keys(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** result) {
-        PassPlan plan = make_plan(key_bits, C::RBITS);
+    // lo_bit > 0: only the bits [lo_bit, key_bits) are sorted (the input is already ordered by the bits below)
+    static int sort_keys(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** result, int lo_bit = 0) {
+        PassPlan plan = make_plan(key_bits - lo_bit, C::RBITS, lo_bit);
         u64* ghist;
         ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * C::RADIX, (void**)&ghist));
         SortArgs a = {};
@@ -1238,7 +1239,8 @@ struct Sorter {
     // pass read the stream, the remaining passes ping-pong between buf_a and buf_b.
     static int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,
                            uint64_t acgt[4], u64** result) {
-        PassPlan plan = make_plan(2 * src.K - src.lo_bit, C::RBITS, src.lo_bit);
+        const int top = (src.hi_bit > 0 && src.hi_bit < 2 * src.K) ? src.hi_bit : 2 * src.K;     // sort the bits [lo_bit, top)
+        PassPlan plan = make_plan(top - src.lo_bit, C::RBITS, src.lo_bit);
         u64* ghist;
         ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * C::RADIX, (void**)&ghist));
         SortArgs a = {};
@@ -1326,6 +1328,13 @@ int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n,
     *rk = keys; *rv = vals;
     if (n == 0) return ZK_OK;
     ZK_SORT_DISPATCH_V(c->pairs_variant, sort_pairs(c, keys, alt, vals, valt, n, key_bits, rk, rv));
+}
+
+// keys already ordered by their low `lo_bit` bits: LSD passes over the bits above only
+int sort_keys_upper(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, int lo_bit, u64** result) {
+    *result = keys;
+    if (n == 0 || lo_bit >= key_bits) return ZK_OK;
+    ZK_SORT_DISPATCH(c, sort_keys(c, keys, alt, n, key_bits, result, lo_bit));
 }
 
 // pairs already ordered by their low `lo_bit` bits: LSD passes over the bits above only

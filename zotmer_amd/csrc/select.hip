@@ -410,6 +410,31 @@ __global__ __launch_bounds__(SEL_BLOCK) void reduce_by_key_kernel(const u64* __r
     if (threadIdx.x == 0 && tile == st.tiles - 1 && sm.tile_excl + tile_total > cap) atomicOr(st.err, ZK_DERR_CAPACITY);
 }
 
+// how many elements of keys[0, m) differ from their predecessor (m = min(n, 2^18)): the yield a run-length collapse of the
+// array would have, estimated from its head -- after LSD passes over the low bits the head of the array is an unbiased sample
+// of the distinct k-mers with all their copies
+__global__ void sample_heads_kernel(const u64* __restrict__ keys, u64 m, u64* out) {
+    u32 h = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (u64)gridDim.x * blockDim.x)
+        h += (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+    h = wave_sum_u32(h);
+    if ((threadIdx.x & 63) == 0 && h) atomicAdd(out, (u64)h);
+}
+
+int sample_heads(zk_ctx* c, const u64* keys, uint64_t n, uint64_t* sampled, uint64_t* heads) {
+    const uint64_t m = n < (1ull << 18) ? n : (1ull << 18);
+    *sampled = m; *heads = m;
+    if (m == 0) return ZK_OK;
+    u64* d = c->d_scalars + 23;
+    ZK_HIP(c, hipMemsetAsync(d, 0, sizeof(u64), c->stream));
+    hipLaunchKernelGGL(sample_heads_kernel, dim3(64), dim3(256), 0, c->stream, keys, (u64)m, d);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 23, d, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    *heads = c->h_scalars[23];
+    return ZK_OK;
+}
+
 int reduce_by_key(zk_ctx* c, const u64* sorted, const u32* w, uint64_t n, u64* uniq, u32* sums, uint64_t cap, uint64_t* n_out) {
     *n_out = 0;
     if (n == 0) return ZK_OK;

@@ -313,7 +313,10 @@ class Context:
     PROF_TAGS = {"hist_stream": 1, "hist_array": 2, "pass_stream": 3, "pass_keys": 4, "pass_pairs": 5, "rle": 6,
                  "union_sum": 7, "select": 8, "mirror": 9, "intersect": 10, "count_hist": 11}
 
-    def tune(self, sort_variant=None, pairs_variant=None, short_sort=None, side_div=None, xcd_group=None, comm_chunk=None):
+    def tune(self, sort_variant=None, pairs_variant=None, short_sort=None, side_div=None, xcd_group=None, comm_chunk=None,
+             early_collapse=None):
+        if early_collapse is not None:
+            self._check(self.lib.zk_tune(self.h, 7, int(early_collapse)))
         if comm_chunk is not None:
             self._check(self.lib.zk_tune(self.h, 6, int(comm_chunk)))
         if xcd_group is not None:
