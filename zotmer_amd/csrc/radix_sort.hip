@@ -544,6 +544,24 @@ __device__ __forceinline__ u64 lookback_segmented(const SortArgs& a, u32 tile, i
     return base + sum;
 }
 
+// match-any over the digit bits: on return (plo, phi) = the live lanes of the wave that hold the same digit as this lane.
+// All RBITS bits are always tested (bits above the pass's width are zero in every lane, so they change nothing) -- no
+// data- or pass-dependent branch.  Four vector instructions per bit: the bit as 0 / ~0 (v_bfe_i32, kept opaque: left to
+// itself the compiler rebuilds it from a shift, a sign compare and an arithmetic shift), its ballot, and per half ONE
+// three-input boolean op  peers &= ~(ballot ^ bit)  (v_bitop3_b32, truth table 0x90 for a & ~(b ^ c)).
+template <int RBITS>
+__device__ __forceinline__ void match_digit(u32 d, u64 live_mask, u32& plo, u32& phi) {
+    plo = (u32)live_mask; phi = (u32)(live_mask >> 32);
+#pragma unroll
+    for (int b = 0; b < RBITS; b++) {
+        int B;
+        asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(B) : "v"(d), "n"(b));
+        const u64 m = __ballot(B != 0);
+        plo = __builtin_amdgcn_bitop3_b32(plo, (u32)m, (u32)B, 0x90);
+        phi = __builtin_amdgcn_bitop3_b32(phi, (u32)(m >> 32), (u32)B, 0x90);
+    }
+}
+
 template <class C, int SRC, bool PAIRS>
 __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_kernel(SortArgs a) {
     constexpr int BLOCK = C::BLOCK, ITEMS = C::ITEMS, RADIX = C::RADIX, NW = C::NW, DPT = C::DPT;
@@ -580,15 +598,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_kernel(SortArgs a) {
         // match-any over the digit bits: peers = live lanes of the wave holding the same digit.
         // All RBITS bits are always tested (bits above a.bits are zero in every lane, so they
         // change nothing) -- no data-dependent or pass-dependent branch in the loop.
-        const u64 lm = __ballot(lv);
-        u32 plo = (u32)lm, phi = (u32)(lm >> 32);
-#pragma unroll
-        for (int b = 0; b < C::RBITS; b++) {
-            const u32 B = (u32)__builtin_amdgcn_sbfe((int)d, b, 1);   // 0 or ~0
-            const u64 m = __ballot(B != 0);
-            plo &= ~((u32)m ^ B);
-            phi &= ~((u32)(m >> 32) ^ B);
-        }
+        u32 plo, phi;
+        match_digit<C::RBITS>(d, __ballot(lv), plo, phi);
         const u32 below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
         const u32 npeer = (u32)__popc(plo) + (u32)__popc(phi);
         const u32 pre = lv ? (u32)mycnt[d] : 0u;
@@ -943,15 +954,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
             for (int i = 0; i < ITEMS; i++) {
                 const bool lv = (live >> i) & 1u;
                 const u32 d = (u32)(key[i] >> a.shift) & dmask;
-                const u64 lm = __ballot(lv);
-                u32 plo = (u32)lm, phi = (u32)(lm >> 32);
-#pragma unroll
-                for (int b = 0; b < C::RBITS; b++) {
-                    const u32 B = (u32)__builtin_amdgcn_sbfe((int)d, b, 1);
-                    const u64 m = __ballot(B != 0);
-                    plo &= ~((u32)m ^ B);
-                    phi &= ~((u32)(m >> 32) ^ B);
-                }
+                u32 plo, phi;
+                match_digit<C::RBITS>(d, __ballot(lv), plo, phi);
                 const u32 below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
                 const u32 npeer = (u32)__popc(plo) + (u32)__popc(phi);
                 const u32 pre = lv ? (u32)mycnt[d] : 0u;

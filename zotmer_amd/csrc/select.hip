@@ -358,27 +358,38 @@ int rle_prefix(zk_ctx* c, const u64* sorted, uint64_t n, int pshift, u64* uniq, 
 
 // ---------------------------------------------------------------------------------------
 // sum the payloads of equal adjacent keys: (sorted keys with duplicates, w) -> (distinct keys, sums).
-// Element i belongs to run number (heads up to and including i) - 1; its weight goes there with one
-// atomic add (runs are short: a k-mer and its mirror, or the pieces of a run that crossed tiles).
+// Element i belongs to run number (heads up to and including i) - 1.  Inside a tile the weights of a run meet in one LDS
+// word (LDS atomics; runs are short: the pieces of a run that the early collapse split, or a k-mer and its mirror), every
+// run that starts in the tile is then written once with plain stores; the leading elements of a tile that continue the
+// previous tile's last run leave their sum in lead[tile] and a second launch adds it where it belongs (as rle_fixup does).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SEL_BLOCK) void reduce_by_key_kernel(const u64* __restrict__ keys, const u32* __restrict__ w, u64 n,
-                                                                  u64* __restrict__ uniq, u32* sums, u64 cap, SelState st) {
-    __shared__ SelSmem sm;
+struct RbkSmem {
+    SelSmemT<RLE_NW> sel;
+    u32 sum[RLE_TILE];        // per run that starts in this tile: sum of its weights inside the tile
+    u32 lead;                 // sum of the weights of the leading elements that belong to the previous tile's run
+};
+
+__global__ __launch_bounds__(RLE_BLOCK) void reduce_by_key_kernel(const u64* __restrict__ keys, const u32* __restrict__ w, u64 n,
+                                                                  u64* __restrict__ uniq, u32* __restrict__ sums, u64 cap,
+                                                                  u32* __restrict__ lead, SelState st) {
+    __shared__ RbkSmem sm;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u32 tile = take_ticket(st.ticket, &sm.ticket) - st.ticket_base;
-    const u64 base = (u64)tile * SEL_TILE + (u64)wave * (64 * SEL_ITEMS);
-    u64 k[SEL_ITEMS];
-    u32 wt[SEL_ITEMS];
-    u64 hm[SEL_ITEMS];
+    const u32 tile = take_ticket(st.ticket, &sm.sel.ticket) - st.ticket_base;
+    const u64 base = (u64)tile * RLE_TILE + (u64)wave * (64 * RLE_ITEMS);
+    for (int i = threadIdx.x; i < RLE_TILE; i += RLE_BLOCK) sm.sum[i] = 0;
+    if (threadIdx.x == 0) sm.lead = 0;
+    u64 k[RLE_ITEMS];
+    u32 wt[RLE_ITEMS];
+    u64 hm[RLE_ITEMS];
     u32 wave_total = 0;
 #pragma unroll
-    for (int i = 0; i < SEL_ITEMS; i++) {
+    for (int i = 0; i < RLE_ITEMS; i++) {
         const u64 idx = base + (u64)i * 64 + lane;
         k[i] = (idx < n) ? keys[idx] : 0ull;
         wt[i] = (idx < n) ? w[idx] : 0u;
     }
 #pragma unroll
-    for (int i = 0; i < SEL_ITEMS; i++) {
+    for (int i = 0; i < RLE_ITEMS; i++) {
         const u64 idx = base + (u64)i * 64 + lane;
         u64 prev = __shfl_up(k[i], 1, 64);
         if (i > 0) {
@@ -392,22 +403,70 @@ __global__ __launch_bounds__(SEL_BLOCK) void reduce_by_key_kernel(const u64* __r
         wave_total += (u32)__popcll(hm[i]);
     }
     u32 tile_total;
-    u64 q = select_wave_base(sm, st, tile, wave_total, &tile_total);
+    const u64 wbase = select_wave_base(sm.sel, st, tile, wave_total, &tile_total);      // barriers inside: sm.sum is zeroed
+    const u64 tile_first = sm.sel.tile_excl;                  // output slot of the first run that starts in this tile
+    u32 q = (u32)(wbase - tile_first);                         // runs started in the tile before this wave's first row
 #pragma unroll
-    for (int i = 0; i < SEL_ITEMS; i++) {
+    for (int i = 0; i < RLE_ITEMS; i++) {
         const u64 idx = base + (u64)i * 64 + lane;
         if (idx < n) {
-            const u64 incl = q + popc_below(hm[i]) + ((hm[i] >> lane) & 1ull);     // heads up to and including me
-            const u64 run = incl - 1;                                              // incl >= 1: element 0 is a head
-            if (run < cap) {
-                if ((hm[i] >> lane) & 1ull) uniq[run] = k[i];
-                const u32 old = atomicAdd(&sums[run], wt[i]);
-                if (old + wt[i] < old) atomicOr(st.err, ZK_DERR_COUNT_OVERFLOW);
-            }
+            const u32 incl = q + popc_below(hm[i]) + (u32)((hm[i] >> lane) & 1ull);     // heads of the tile up to and including me
+            u32 old;
+            if (incl == 0) old = atomicAdd(&sm.lead, wt[i]);
+            else old = atomicAdd(&sm.sum[incl - 1], wt[i]);
+            if (old + wt[i] < old) atomicOr(st.err, ZK_DERR_COUNT_OVERFLOW);
         }
         q += (u32)__popcll(hm[i]);
     }
-    if (threadIdx.x == 0 && tile == st.tiles - 1 && sm.tile_excl + tile_total > cap) atomicOr(st.err, ZK_DERR_CAPACITY);
+    __syncthreads();
+    q = (u32)(wbase - tile_first);
+#pragma unroll
+    for (int i = 0; i < RLE_ITEMS; i++) {
+        if ((hm[i] >> lane) & 1ull) {
+            const u32 r = q + popc_below(hm[i]);
+            const u64 pos = tile_first + r;
+            if (pos < cap) { uniq[pos] = k[i]; sums[pos] = sm.sum[r]; }
+        }
+        q += (u32)__popcll(hm[i]);
+    }
+    if (threadIdx.x == 0) {
+        lead[tile] = sm.lead;
+        if (tile == st.tiles - 1 && tile_first + tile_total > cap) atomicOr(st.err, ZK_DERR_CAPACITY);
+    }
+}
+
+// sums[(first output slot of tile t) - 1] += lead[t]
+__global__ void reduce_fixup_kernel(const u32* __restrict__ lead, const u64* __restrict__ status, u32 tiles, u32* sums, u64 cap, u32* err) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 || t >= tiles) return;
+    const u32 l = lead[t];
+    if (l == 0) return;
+    const u64 excl = status[t - 1] & ZK_ST_VALUE_MASK;   // inclusive prefix of the tile before = first slot of this tile
+    if (excl == 0 || excl - 1 >= cap) return;
+    const u32 old = atomicAdd(&sums[excl - 1], l);
+    if (old + l < old) atomicOr(err, ZK_DERR_COUNT_OVERFLOW);
+}
+
+int reduce_by_key(zk_ctx* c, const u64* sorted, const u32* w, uint64_t n, u64* uniq, u32* sums, uint64_t cap, uint64_t* n_out) {
+    *n_out = 0;
+    if (n == 0) return ZK_OK;
+    SelState st;
+    st.tiles = (u32)div_up(n, RLE_TILE);
+    u32* lead;
+    ZK_TRY(arena_alloc(c, sizeof(u32) * st.tiles, (void**)&lead));
+    ZK_TRY(lookback_begin(c, st.tiles, st.tiles, &st.epoch, &st.ticket_base));
+    st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9;
+    prof_begin(c, ZK_PROF_SELECT, 12 * n);
+    hipLaunchKernelGGL(reduce_by_key_kernel, dim3(st.tiles), dim3(RLE_BLOCK), 0, c->stream, sorted, w, (u64)n, uniq, sums, (u64)cap, lead, st);
+    prof_end(c);
+    ZK_HIP(c, hipGetLastError());
+    hipLaunchKernelGGL(reduce_fixup_kernel, dim3((u32)div_up(st.tiles, 256)), dim3(256), 0, c->stream, lead, c->status, st.tiles, sums,
+                       (u64)cap, c->d_err);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, c->d_scalars + 9, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    *n_out = c->h_scalars[9];
+    return check_device_error(c);
 }
 
 // how many elements of keys[0, m) differ from their predecessor (m = min(n, 2^18)): the yield a run-length collapse of the
@@ -433,24 +492,6 @@ int sample_heads(zk_ctx* c, const u64* keys, uint64_t n, uint64_t* sampled, uint
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     *heads = c->h_scalars[23];
     return ZK_OK;
-}
-
-int reduce_by_key(zk_ctx* c, const u64* sorted, const u32* w, uint64_t n, u64* uniq, u32* sums, uint64_t cap, uint64_t* n_out) {
-    *n_out = 0;
-    if (n == 0) return ZK_OK;
-    SelState st;
-    st.tiles = (u32)div_up(n, SEL_TILE);
-    ZK_TRY(lookback_begin(c, st.tiles, st.tiles, &st.epoch, &st.ticket_base));
-    st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9;
-    ZK_HIP(c, hipMemsetAsync(sums, 0, sizeof(u32) * (n < cap ? n : cap), c->stream));
-    prof_begin(c, ZK_PROF_SELECT, 12 * n);
-    hipLaunchKernelGGL(reduce_by_key_kernel, dim3(st.tiles), dim3(SEL_BLOCK), 0, c->stream, sorted, w, (u64)n, uniq, sums, (u64)cap, st);
-    prof_end(c);
-    ZK_HIP(c, hipGetLastError());
-    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, c->d_scalars + 9, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    ZK_HIP(c, hipStreamSynchronize(c->stream));
-    *n_out = c->h_scalars[9];
-    return check_device_error(c);
 }
 
 // counts[(first output index of tile t) - 1] += lead[t]
