@@ -85,16 +85,37 @@ __global__ __launch_bounds__(MRG_BLOCK) void union_sum_kernel(const u64* __restr
     u64* const kb = sm.in.keys + nAt + 2;
     CT* const ca = sm.in.cnts;
     CT* const cb = sm.in.cnts + nAt + 2;
-    // stage: ka[1 + i] = A[a0 + i], ka[0] = A[a0 - 1]; kb[j] = B[b0 + j], kb[nBt] = B[b1]
-    for (int i = tid; i < nAt + 1; i += MRG_BLOCK) {
-        const u64 g = a0 + i;           // element index + 1
-        ka[i] = (g >= 1) ? A[g - 1] : 0ull;
-        ca[i] = (g >= 1) ? cA[g - 1] : (CT)0;
-    }
-    for (int j = tid; j < nBt + 1; j += MRG_BLOCK) {
-        const u64 g = b0 + j;
-        kb[j] = (g < nB) ? B[g] : 0ull;
-        cb[j] = (g < nB) ? cB[g] : (CT)0;
+    // stage: ka[1 + i] = A[a0 + i], ka[0] = A[a0 - 1]; kb[j] = B[b0 + j], kb[nBt] = B[b1].  One flat index space over both
+    // slices, a fixed number of rounds, every load of a thread issued before the first LDS write: written as two loops over
+    // the slices the loads came out one global round trip per iteration (load, wait, ds_write, next), up to sixteen in a row
+    // -- that, not the merge, was the tile's time.
+    {
+        constexpr int R = (MRG_TILE + 2 + MRG_BLOCK - 1) / MRG_BLOCK;
+        const u64* safe_k = nA ? A : B;
+        const CT* safe_c = nA ? cA : cB;
+        u64 kv[R];
+        CT cv[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int sl = tid + r * MRG_BLOCK;
+            const bool isA = sl <= nAt;
+            const u64 g = isA ? a0 + (u64)sl : b0 + (u64)(sl - nAt - 1);          // A side: element index + 1
+            const bool ok = (sl < nAt + nBt + 2) && (isA ? g >= 1 : g < nB);
+            const u64* pk = ok ? (isA ? A + (g - 1) : B + g) : safe_k;
+            const CT* pc = ok ? (isA ? cA + (g - 1) : cB + g) : safe_c;
+            kv[r] = *pk;
+            cv[r] = *pc;
+            if (!ok) { kv[r] = 0; cv[r] = 0; }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int sl = tid + r * MRG_BLOCK;
+            if (sl < nAt + nBt + 2) {
+                const int at = (sl <= nAt) ? sl : sl + 1;       // the B side starts at keys + nAt + 2
+                sm.in.keys[at] = kv[r];
+                sm.in.cnts[at] = cv[r];
+            }
+        }
     }
     __syncthreads();
     const bool have_left = a0 > 0;
@@ -210,8 +231,26 @@ __global__ __launch_bounds__(MRG_BLOCK) void intersect_kernel(const u64* __restr
     if (d1 > nA + nB) d1 = nA + nB;
     const u64 b0 = d0 - a0, b1 = d1 - a1;
     const int nAt = (int)(a1 - a0), nBt = (int)(b1 - b0);
-    for (int i = tid; i < nAt + 1; i += MRG_BLOCK) { const u64 g = a0 + i; ka[i] = (g >= 1) ? A[g - 1] : 0ull; }
-    for (int j = tid; j < nBt; j += MRG_BLOCK) kb[j] = B[b0 + j];
+    {
+        // all loads of a thread before its first LDS write (see union_sum_kernel)
+        constexpr int R = (MRG_TILE + 1 + MRG_BLOCK - 1) / MRG_BLOCK;
+        u64 kv[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int sl = tid + r * MRG_BLOCK;
+            const bool isA = sl <= nAt;
+            const u64 g = isA ? a0 + (u64)sl : b0 + (u64)(sl - nAt - 1);
+            const bool ok = (sl < nAt + 1 + nBt) && (isA ? g >= 1 : true);
+            kv[r] = *(ok ? (isA ? A + (g - 1) : B + g) : A);
+            if (!ok) kv[r] = 0;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int sl = tid + r * MRG_BLOCK;
+            if (sl <= nAt) ka[sl] = kv[r];
+            else if (sl < nAt + 1 + nBt) kb[sl - nAt - 1] = kv[r];
+        }
+    }
     __syncthreads();
     const bool have_left = a0 > 0;
     const int total = nAt + nBt;
