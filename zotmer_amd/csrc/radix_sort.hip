@@ -27,12 +27,6 @@
 
 namespace zk {
 
-#ifndef ZK_PIPE_EARLY_LOAD
-#define ZK_PIPE_EARLY_LOAD 1
-#endif
-#ifndef ZK_PIPE_EARLY_ROWS
-#define ZK_PIPE_EARLY_ROWS 4
-#endif
 constexpr int MAX_PASSES = 8;
 constexpr int MAX_RADIX = 1024;
 
@@ -230,21 +224,19 @@ template <class C, int SRC> struct NextTile;
 template <class C> struct NextTile<C, SRC_ARRAY> {
     u64 key[C::ITEMS];
     u32 live = 0;
-    // rows [I0, I1) of the tile
-    template <int I0 = 0, int I1 = C::ITEMS>
     __device__ __forceinline__ void issue(const SortArgs& a, u32 t, int tid, int wave, int lane) {
         const u64 base = (u64)t * C::TILE + (u64)wave * (64 * C::ITEMS) + lane;
-        if (I0 == 0) live = 0;
         if ((u64)(t + 1) * C::TILE <= a.n) {
             // a whole tile (all but the last): one address, constant offsets, no per-key bound checks
             const u64* p = a.kin + base;
 #pragma unroll
-            for (int i = I0; i < I1; i++) key[i] = p[i * 64];
+            for (int i = 0; i < C::ITEMS; i++) key[i] = p[i * 64];
             live = (C::ITEMS >= 32) ? ~0u : ((1u << C::ITEMS) - 1u);
             return;
         }
+        live = 0;
 #pragma unroll
-        for (int i = I0; i < I1; i++) {
+        for (int i = 0; i < C::ITEMS; i++) {
             const u64 idx = base + (u64)i * 64;
             const bool ok = idx < a.n;
             key[i] = ok ? a.kin[idx] : 0ull;
@@ -254,7 +246,6 @@ template <class C> struct NextTile<C, SRC_ARRAY> {
 };
 template <class C> struct NextTile<C, SRC_STREAM> {
     uint4 q0, q1;        // this thread's 16-byte chunk(s) of the tile's stream bytes
-    template <int I0 = 0, int I1 = 0>
     __device__ __forceinline__ void issue(const SortArgs& a, u32 t, int tid, int wave, int lane) {
         const u64 t0 = a.rec ? (u64)t * a.rpt * a.rec : (u64)t * C::TILE;
         const u32 nch = a.rec ? (a.rpt * a.rec) / 16 + 3 : (u32)TileImage<C::TILE>::NCH;
@@ -799,8 +790,6 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 dmask = (1u << a.bits) - 1u;
     u16* mycnt = sm.cnt[wave];
-    constexpr bool EARLY_LOAD = ZK_PIPE_EARLY_LOAD && SRC == SRC_ARRAY;      // array source only (the stream variant has no registers to spare)
-    constexpr int EARLY_ROWS = ZK_PIPE_EARLY_ROWS;
 
     // ---- the first NS tickets are the scanners ------------------------------------------------------
     // A scanner workgroup owns 64 digits (one per lane).  Its NW waves take the tiles in batches of U, wave w
@@ -990,16 +979,6 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
             __syncthreads();
             tC = (u32)__builtin_amdgcn_readfirstlane((int)sm.ticket);
             vC = tC < tiles;
-            if constexpr (EARLY_LOAD) {
-                // The first rows of C are asked for NOW: their round trip runs under B's digit scan, A's stores and the
-                // parking of B instead of in front of the next ranking, which consumes its keys row by row (counted
-                // vmcnt waits), so the rows asked for at the end of the iteration arrive while the first ones are
-                // ranked.  All sixteen rows this early do not fit the registers (they spilled: 52 bytes of scratch).
-                if (vC) {
-                    if (tid == 0) pending = atomicAdd(a.xticket + 32 * myx, 1u);
-                    nx.template issue<0, EARLY_ROWS>(a, tC, tid, wave, lane);
-                }
-            }
             // ---- per digit: scan over the waves, publish the tile's count at once -------------------
             u32 tsum = 0;
 #pragma unroll
@@ -1109,12 +1088,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
         // Loading C any earlier (while B's keys and ranks are live) costs more in spilled registers than
         // the hidden latency gives back (measured: 2.87 vs 3.13 TB/s), so the loads start here.
         if (vB) {
-            if constexpr (EARLY_LOAD) {
-                nx.template issue<EARLY_ROWS, ITEMS>(a, tB, tid, wave, lane);
-            } else {
-                if (tid == 0) pending = atomicAdd(a.xticket + 32 * myx, 1u);
-                issue_loads(tB);
-            }
+            if (tid == 0) pending = atomicAdd(a.xticket + 32 * myx, 1u);
+            issue_loads(tB);
         }
     }
 }
