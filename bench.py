@@ -462,11 +462,17 @@ def main():
         out_k, out_c = ctx.empty(cap, np.uint64), ctx.empty(cap, np.uint32)
 
     def step():
-        k, c, st = ctx.kmerize(stream, K, flags, out=(out_k, out_c))
-        if par is not None:
-            if par.owner == "range":
-                par.balanced_cuts([(kt, k.n)])
-            k, c = par.exchange_and_merge(kt, ct, k.n)
+        if par is not None and not a.both:
+            # the counted canonical lists are exchanged (half the size of the both-strand tables) and each rank rebuilds the
+            # strands of the k-mers whose canonical form it owns: parallel.Exchange.kmerize_finish
+            k, c, st = ctx.kmerize(stream, K, flags | native.KMERIZE_CANONICAL_ONLY, out=(out_k, out_c))
+            k, c = par.kmerize_finish(kt, ct, k.n)
+        else:
+            k, c, st = ctx.kmerize(stream, K, flags, out=(out_k, out_c))
+            if par is not None:
+                if par.owner == "range":
+                    par.balanced_cuts([(kt, k.n)])
+                k, c = par.exchange_and_merge(kt, ct, k.n)
         h = ctx.hist(c)
         return k, c, st, h
 

@@ -137,6 +137,9 @@ int zk_sort_count(zk_ctx* ctx, uint64_t* d_keys, uint64_t n, int key_bits,
 #define ZK_KMERIZE_CANONICAL 0   /* default: sort one strand, mirror after counting (same result) */
 #define ZK_KMERIZE_BOTH 1        /* sort both strands literally, as the reference does */
 #define ZK_KMERIZE_SUBSAMPLE 2   /* -D FRAC -S SEED (commands/kmerize.py:469-478,494-509) */
+#define ZK_KMERIZE_CANONICAL_ONLY 4   /* stop before the strands are rebuilt: d_kmers / d_counts get the counted CANONICAL list
+                                         (c = min(x, rc x) per window, count = windows), n_unique = its length.  The multi-GPU
+                                         path exchanges this half-size list and calls zk_mirror_expand on what a rank owns. */
 
 typedef struct {
     uint64_t n_windows;     /* valid windows seen */
@@ -150,6 +153,13 @@ typedef struct {
  * the base stream: sorted distinct k-mers of BOTH strands and their counts. */
 int zk_kmerize(zk_ctx* ctx, const uint8_t* d_stream, uint64_t n_bytes, int K, int flags, double p, uint64_t seed,
                uint64_t* d_kmers, uint32_t* d_counts, uint64_t cap, zk_kmerize_stats* stats);
+
+/* The second half of zk_kmerize for a counted canonical list (ascending c, counts): sorted distinct k-mers of BOTH strands
+ * -- (c, n) and (rc c, n) for every entry, a palindrome (c == rc c) counted n + n, as two emissions per window give
+ * (commands/kmerize.py:490; library/reads.py:113-114).  zk_kmerize(flags) == zk_mirror_expand(zk_kmerize(flags |
+ * ZK_KMERIZE_CANONICAL_ONLY)). */
+int zk_mirror_expand(zk_ctx* ctx, const uint64_t* d_canon_kmers, const uint32_t* d_canon_counts, uint64_t n, int K,
+                     uint64_t* d_kmers, uint32_t* d_counts, uint64_t cap, uint64_t* n_out);
 
 /* hist[c] += 1 per distinct k-mer (commands/kmerize.py:543-545; merge.py:88-92), as ascending
  * (value, frequency) pairs in HOST arrays of cap_bins entries.  count_bits is 32 or 64. */

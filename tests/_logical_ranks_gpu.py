@@ -117,6 +117,19 @@ def worker(rank, owner, host_sets, results):
                 pieces.append((torch.from_numpy(ch.view(np.int64).copy()).cuda() if len(ch) else torch.empty(1, dtype=torch.int64, device="cuda"), len(ch)))
             abc, sizes = exd.dist_pair(pieces[0][0], pieces[0][1], pieces[1][0], pieces[1][1], shift=2 * (K - kk))
             out["abc%d" % kk], out["sz%d" % kk] = abc, sizes
+        # kmerize: every rank counts its own reads as a CANONICAL list, the lists are exchanged, the owner rebuilds the strands
+        R = 2500
+        kw = dict(genome=40000, sub_thr=synth.frac32(0.005), n_thr=synth.frac32(0.0005))
+        d = ctx.synth_reads(synth.DEFAULT_SEED, rank * R, R, 150, **kw)
+        ck, cc, st = ctx.kmerize(d, K, native.KMERIZE_CANONICAL_ONLY)
+        exk = parallel.Exchange(ctx, None, K, owner=owner, seed=11, comm=comm)
+        kt, ct, n = exk.ops.to_tensors(ck, cc)
+        bk, bc = exk.kmerize_finish(kt, ct, n)
+        assert exk.verify_global(bk, bc, ctx.stream_checksum(d, K)), "kmerize: checksum of checksums"
+        out["kz_owned"] = bk.n
+        gk, gc = exk.gather_to_root(bk, bc)
+        if rank == 0:
+            out["kz_k"], out["kz_c"] = gk.to_host(), gc.to_host()
         results[rank] = out
         ctx.close()
     except BaseException as e:          # noqa: BLE001
@@ -155,7 +168,16 @@ def main():
                 pa, pb = zo.project_dedupe(host_sets[0][0], 2 * (K - kk)), zo.project_dedupe(host_sets[1][0], 2 * (K - kk))
                 assert tuple(int(v) for v in r["abc%d" % kk]) == zo.split(pa, pb), (owner, kk)
                 assert tuple(int(v) for v in r["sz%d" % kk]) == (len(pa), len(pb))
-        print("LOGICAL-RANKS-OK", owner, len(zs), sizes)
+        R = 2500
+        kw = dict(genome=40000, sub_thr=synth.frac32(0.005), n_thr=synth.frac32(0.0005))
+        reads = []
+        for r in range(W):
+            reads += synth.read_strings(synth.DEFAULT_SEED, r * R, R, 150, **kw)
+        wantk = zo.kmerize(K, reads)
+        assert np.array_equal(r0["kz_k"], wantk["kmers"]) and np.array_equal(r0["kz_c"], wantk["counts"]), owner + ": kmerize over 8 ranks"
+        ksz = [r["kz_owned"] for r in results]
+        assert sum(ksz) == len(wantk["kmers"]) and max(ksz) <= 1.25 * len(wantk["kmers"]) / W, (owner, ksz)
+        print("LOGICAL-RANKS-OK", owner, len(zs), sizes, ksz)
 
 
 if __name__ == "__main__":

@@ -308,6 +308,36 @@ def test_kmerize_early_collapse_paths_agree(ctx, K):
             ctx.tune(early_collapse=1)
 
 
+@pytest.mark.parametrize("K", [4, 12, 24, 25, 31, 32])
+def test_kmerize_canonical_only_and_mirror_expand(ctx, K):
+    """zk_kmerize(ZK_KMERIZE_CANONICAL_ONLY) = the counted list of c = min(x, rc x); zk_mirror_expand of it = zk_kmerize.
+    Even K has palindromes (counted twice per window in the both-strand table, once in the canonical list)."""
+    reads = synth.read_strings(21, 0, 5000, 120, genome=15000, sub_thr=synth.frac32(0.004), n_thr=synth.frac32(0.002)) + ["ACGT" * 25, "AATT" * 20, "GC" * 50]
+    want = zo.kmerize(K, reads)
+    wk, wc = want["kmers"], want["counts"]
+    rc = np.array([zo.rc(K, int(x)) for x in wk], dtype=np.uint64)
+    keep = wk <= rc
+    ck_want, cc_want = wk[keep], wc[keep].astype(np.uint64)
+    cc_want[wk[keep] == rc[keep]] //= 2
+    d = ctx.upload_stream(stream_of(reads))
+    for collapse in (1, 0):
+        ctx.tune(early_collapse=collapse)
+        try:
+            ck, cc, st = ctx.kmerize(d, K, native.KMERIZE_CANONICAL_ONLY)
+        finally:
+            ctx.tune(early_collapse=1)
+        assert np.array_equal(ck.to_host(), ck_want) and np.array_equal(cc.to_host().astype(np.uint64), cc_want)
+        assert st.n_unique == len(ck_want) and st.n_canonical == len(ck_want) and list(st.acgt) == want["acgt"]
+        k, c = ctx.mirror_expand(ck, cc, K)
+        assert np.array_equal(k.to_host(), wk) and np.array_equal(c.to_host(), wc)
+    e = ctx.empty(0, np.uint64).view(0), ctx.empty(0, np.uint32).view(0)
+    assert ctx.mirror_expand(e[0], e[1], K)[0].n == 0
+    with pytest.raises(native.ZotkError):
+        ctx.kmerize(d, K, native.KMERIZE_CANONICAL_ONLY | native.KMERIZE_BOTH)
+    with pytest.raises(native.ZotkError):
+        ctx.kmerize(d, K, native.KMERIZE_CANONICAL_ONLY | native.KMERIZE_SUBSAMPLE, p=0.5)
+
+
 @pytest.mark.parametrize("case", ["u150", "u150_k13", "u100", "u40", "u255", "alt_149_151", "last_short", "n_at_separator", "one_read"])
 def test_kmerize_record_aligned_tiles_and_fallbacks(ctx, case):
     """Pass 0 lays its tiles along the records when every record has the same length (checked on the device); any other

@@ -87,6 +87,27 @@ class NumpyOps:
     def to_tensors(self, k, c):
         return torch.from_numpy(k.view(np.int64).copy()), torch.from_numpy(c.view(np.int64).copy()), len(k)
 
+    def mirror_expand(self, k, c, K):
+        """both strands of a counted canonical list: (x, n) and (rc x, n), a palindrome counted n + n"""
+        acc = {}
+        for x, n in zip(k, c):
+            x, n = int(x), int(n)
+            acc[x] = acc.get(x, 0) + n
+            y = zo.rc(K, x)
+            acc[y] = acc.get(y, 0) + n
+        ks = np.array(sorted(acc), dtype=np.uint64)
+        return ks, np.array([acc[int(x)] for x in ks], dtype=np.uint64)
+
+
+def canonical_of(table, K):
+    """the counted canonical list zk_kmerize(ZK_KMERIZE_CANONICAL_ONLY) returns, from the oracle's both-strand table"""
+    k, c = table["kmers"], table["counts"]
+    rc = np.array([zo.rc(K, int(x)) for x in k], dtype=np.uint64)
+    keep = k <= rc
+    cc = c[keep].astype(np.uint64)
+    cc[k[keep] == rc[keep]] //= 2                      # a palindrome was emitted twice per window
+    return k[keep], cc.astype(np.uint32)
+
 
 def _reads(rank):
     return synth.read_strings(synth.DEFAULT_SEED, rank * READS_PER_RANK, READS_PER_RANK, 150, **KW)
@@ -116,21 +137,31 @@ def _init(rank, world, port):
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
 
-def _kmerize_worker(rank, world, port, outdir, owner, chunk, skew):
+def _kmerize_worker(rank, world, port, outdir, owner, chunk, skew, canonical=False):
     _init(rank, world, port)
     try:
         reads = _skewed_reads(rank) if skew else _reads(rank)
         local = zo.kmerize(K, reads)
-        n = len(local["kmers"])
-        kt = torch.from_numpy(local["kmers"].view(np.int64).copy())
-        ct = torch.from_numpy(local["counts"].view(np.int32).copy())
         ex = parallel.Exchange(None, dist, K, ops=NumpyOps(), owner=owner, seed=7)
         if chunk:
             ex.CHUNK = chunk          # force several rounds per all-to-all (on the GPU a round is <= 256 MiB per peer)
-        if owner == "range":
-            cuts = ex.balanced_cuts([(kt, n)])
-        k, c = ex.exchange_and_merge(kt, ct, n)
-        if owner == "range":          # every k-mer this rank now owns lies in its value range
+        if canonical:
+            # the product flow of `zot kmerize` / bench.py: canonical lists travel, the owner rebuilds the strands
+            ck, cc = canonical_of(local, K)
+            kt = torch.from_numpy(ck.view(np.int64).copy())
+            ct = torch.from_numpy(cc.view(np.int32).copy())
+            k, c = ex.kmerize_finish(kt, ct, len(ck))
+            assert all((min(int(x), zo.rc(K, int(x))) >= (([0] + ex.cuts + [1 << (2 * K)])[rank]) if owner == "range" else True) for x in k[:100])
+        else:
+            n = len(local["kmers"])
+            kt = torch.from_numpy(local["kmers"].view(np.int64).copy())
+            ct = torch.from_numpy(local["counts"].view(np.int32).copy())
+            if owner == "range":
+                cuts = ex.balanced_cuts([(kt, n)])
+            k, c = ex.exchange_and_merge(kt, ct, n)
+        if canonical:
+            pass
+        elif owner == "range":          # every k-mer this rank now owns lies in its value range
             edges = [0] + cuts + [1 << (2 * K)]
             assert len(k) == 0 or (int(k[0]) >= edges[rank] and int(k[-1]) < edges[rank + 1])
         else:
@@ -167,6 +198,20 @@ def test_kmerize_exchange_gloo(tmp_path, world, owner, chunk):
     if owner == "range":                                               # concatenation in rank order IS the global sorted set
         assert np.array_equal(np.concatenate([p["k"] for p in parts]), want["kmers"])
         assert np.array_equal(np.concatenate([p["c"] for p in parts]), want["counts"].astype(np.uint64))
+    sizes = [len(p["k"]) for p in parts]
+    assert max(sizes) <= 1.2 * (sum(sizes) / world)
+
+
+@pytest.mark.parametrize("world,owner,chunk", [(2, "range", 900), (3, "hash", None), (3, "range", None)])
+def test_kmerize_canonical_exchange_gloo(tmp_path, world, owner, chunk):
+    """Exchange.kmerize_finish: the counted CANONICAL lists are exchanged and every rank rebuilds both strands of what it owns"""
+    mp.spawn(_kmerize_worker, args=(world, _free_port(), str(tmp_path), owner, chunk, False, True), nprocs=world, join=True)
+    parts = [np.load(str(tmp_path / ("r%d.npz" % r))) for r in range(world)]
+    want = zo.kmerize(K, [s for r in range(world) for s in _reads(r)])
+    root = np.load(str(tmp_path / "root.npz"))
+    assert np.array_equal(root["k"], want["kmers"])
+    assert np.array_equal(root["c"], want["counts"].astype(np.uint64))
+    assert sum(len(p["k"]) for p in parts) == len(want["kmers"])          # the pieces partition the table
     sizes = [len(p["k"]) for p in parts]
     assert max(sizes) <= 1.2 * (sum(sizes) / world)
 

@@ -130,11 +130,12 @@ def main(argv):
     if verbose:
         sys.stderr.write("\n")
 
-    kmers, counts, hist = table.device_result()
     if dist is not None:
-        kmers, counts, hist = _gather_distributed(ctx, dist, K, table, kmers, counts)
+        kmers, counts, hist = _gather_distributed(ctx, dist, K, table)
         if rank != 0:
             return
+    else:
+        kmers, counts, hist = table.device_result()
     with KmerSet(out, "w") as z:                    # kmerize.py:541-561; delta + codec64 done on the device
         vectors.device_write_kmers_and_counts(ctx, z, kmers, counts)
         total = float(sum(table.acgt))
@@ -149,16 +150,22 @@ def main(argv):
                          % (t_parse, t_gpu, time.perf_counter() - t0))
 
 
-def _gather_distributed(ctx, dist, K, table, kmers, counts):
-    """The ranks' tables meet in one exchange by k-mer owner (zotmer_amd/parallel.py), acgt is all-reduced, and rank 0
-    gathers the owned pieces to write the one output file."""
+def _gather_distributed(ctx, dist, K, table):
+    """The ranks' tables meet in one exchange by k-mer owner (zotmer_amd/parallel.py): canonical lists when there is no -D
+    (half the bytes; the strands are rebuilt on the owner), acgt is all-reduced, and rank 0 gathers the owned pieces to
+    write the one output file."""
     from zotmer_amd import parallel
     comm = parallel.make_comm(ctx, dist)
     ex = parallel.Exchange(ctx, dist, K, owner=os.environ.get("ZOT_OWNER", "range"), comm=comm)
-    kt, ct, n = ex.ops.to_tensors(kmers, counts)
-    if ex.owner == "range":
-        ex.balanced_cuts([(kt, n)])
-    k, c = ex.exchange_and_merge(kt, ct, n)
+    if table.canonical:
+        kt, ct, n = ex.ops.to_tensors(*table.canonical_result())
+        k, c = ex.kmerize_finish(kt, ct, n)
+    else:
+        kmers, counts, _ = table.device_result()
+        kt, ct, n = ex.ops.to_tensors(kmers, counts)
+        if ex.owner == "range":
+            ex.balanced_cuts([(kt, n)])
+        k, c = ex.exchange_and_merge(kt, ct, n)
     table.acgt = comm.all_reduce(table.acgt)
     gk, gc = ex.gather_to_root(k, c)
     if comm.rank != 0:

@@ -9,6 +9,7 @@ int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, dou
 int merge_many(zk_ctx* c, int k, const u64* const* keys, const void* const* cnts, const uint64_t* ns, u64* out_k, void* out_c,
                int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);
 int widen_counts(zk_ctx* c, const u32* in, u64* out, uint64_t n);
+int mirror_expand(zk_ctx* c, const u64* ck, const u32* cc, uint64_t n, int K, u64* out_k, u32* out_c, uint64_t cap, uint64_t* n_out);
 
 // ---- (bases, offsets) -> base stream ----------------------------------------------------------
 __global__ void pack_reads_kernel(const u8* __restrict__ bases, const u64* __restrict__ offs, u64 n_reads, u8* __restrict__ out) {
@@ -195,6 +196,12 @@ int zk_kmerize(zk_ctx* c, const uint8_t* d_stream, uint64_t n_bytes, int K, int 
                uint64_t* d_kmers, uint32_t* d_counts, uint64_t cap, zk_kmerize_stats* stats) {
     ZK_ARGS(c, stats);
     return kmerize(c, d_stream, n_bytes, K, flags, p, seed, (u64*)d_kmers, d_counts, cap, stats);
+}
+
+int zk_mirror_expand(zk_ctx* c, const uint64_t* d_ck, const uint32_t* d_cc, uint64_t n, int K, uint64_t* d_kmers, uint32_t* d_counts,
+                     uint64_t cap, uint64_t* n_out) {
+    ZK_ARGS(c, n_out && (n == 0 || (d_ck && d_cc && d_kmers && d_counts)));
+    return mirror_expand(c, (const u64*)d_ck, d_cc, n, K, (u64*)d_kmers, d_counts, cap, n_out);
 }
 
 int zk_hist(zk_ctx* c, const void* d_counts, int count_bits, uint64_t n, uint64_t* vals, uint64_t* freq, uint64_t cap_bins,

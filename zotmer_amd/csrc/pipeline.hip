@@ -120,6 +120,52 @@ __global__ void side_expand_kernel(const u64* __restrict__ k, const u32* __restr
 
 static int ilog2_ceil(uint64_t x) { int b = 0; while ((1ull << b) < x && b < 63) b++; return b; }
 
+// Both strands from the counted canonical list (c, n), c ascending: the pairs (rc c, n) are sorted by key and union-summed
+// with (c, n); a palindrome (c == rc c, even K) meets itself there and gets n + n -- two emissions per window, as the
+// reference has them (commands/kmerize.py:490, library/reads.py:113-114).  rk / rk2 (8 bytes per entry) and rv / rv2 (4) are
+// work buffers; start / dest tables come from the arena.
+static int mirror_union(zk_ctx* c, const u64* sorted, const u32* cnt, uint64_t uc, int K, u64* rk, u64* rk2, u32* rv, u32* rv2,
+                        u64* out_k, u32* out_c, uint64_t cap, uint64_t* n_out) {
+    u64* sk; u32* sv;
+    if (2 * K >= MIRROR_GROUP_BITS + 8 && uc >= (1ull << 16)) {
+        // The list (c, n) is sorted by c, so the k-mers that share their first 9 bases are contiguous -- and those are
+        // exactly the mirrored keys rc(c) that share their LAST 9 bases, i.e. their low 18 bits.  The first two passes of
+        // an LSD sort of the mirrored keys would only move these 2^18 groups around whole; one copy does it: group
+        // boundaries by binary search, group order = order of the reversed-complemented prefix, then only the bits
+        // above 18 are sorted.
+        u64 *start, *dest;
+        ZK_TRY(arena_alloc(c, sizeof(u64) * ((1u << MIRROR_GROUP_BITS) + 1), (void**)&start));
+        ZK_TRY(arena_alloc(c, sizeof(u64) * (1u << MIRROR_GROUP_BITS), (void**)&dest));
+        prof_begin(c, ZK_PROF_MIRROR, 24 * uc);
+        hipLaunchKernelGGL(mirror_bounds_kernel, dim3(((1u << MIRROR_GROUP_BITS) + 256) / 256), dim3(256), 0, c->stream, sorted, (u64)uc, K, start);
+        hipLaunchKernelGGL(mirror_sizes_kernel, dim3((1u << MIRROR_GROUP_BITS) / 256), dim3(256), 0, c->stream, start, dest);
+        hipLaunchKernelGGL(mirror_scan_kernel, dim3(1), dim3(1024), 0, c->stream, dest);
+        hipLaunchKernelGGL(mirror_copy_kernel, dim3(ew_grid(c, uc)), dim3(256), 0, c->stream, sorted, cnt, (u64)uc, K, start, dest, rk, rv);
+        prof_end(c);
+        ZK_HIP(c, hipGetLastError());
+        ZK_TRY(sort_pairs_upper(c, rk, rk2, rv, rv2, uc, 2 * K, MIRROR_GROUP_BITS, &sk, &sv));
+    } else {
+        // small inputs / short k-mers: the histogram and the first pass of the sort read (c, n) and reverse-complement on load
+        ZK_TRY(sort_pairs_mirrored(c, sorted, cnt, rk, rk2, rv, rv2, uc, K, &sk, &sv));
+    }
+    return union_sum(c, sorted, cnt, uc, sk, sv, uc, out_k, out_c, 32, cap, n_out, nullptr);
+}
+
+// zk_mirror_expand: the strands of an already counted canonical list (multi-GPU: after the exchange)
+int mirror_expand(zk_ctx* c, const u64* ck, const u32* cc, uint64_t n, int K, u64* out_k, u32* out_c, uint64_t cap, uint64_t* n_out) {
+    *n_out = 0;
+    if (K < 1 || K > 32) return fail(c, ZK_EINVAL, "K must be in 1..32 (got %d)", K);
+    if (n == 0) return ZK_OK;
+    arena_reset(c);
+    const uint64_t a8 = (8 * n + 255) & ~255ull, a4 = (4 * n + 255) & ~255ull;
+    const uint64_t need = 2 * a8 + 2 * a4 + (9 << 20) + n / 8;          // work buffers, group tables, histograms, merge-path partition
+    ZK_TRY(arena_require(c, need, need));
+    char* w;
+    ZK_TRY(arena_alloc(c, 2 * a8 + 2 * a4, (void**)&w));
+    ZK_TRY(mirror_union(c, ck, cc, n, K, (u64*)w, (u64*)(w + a8), (u32*)(w + 2 * a8), (u32*)(w + 2 * a8 + a4), out_k, out_c, cap, n_out));
+    return check_device_error(c);
+}
+
 // The literal paths: every bit sorted, then RLE; canonical keys are mirrored afterwards.
 //
 // Early collapse (canonical mode).  Sequencing reads repeat every k-mer `coverage` times, and an LSD sort drags all those
@@ -131,7 +177,7 @@ static int ilog2_ceil(uint64_t x) { int b = 0; while ((1ull << b) < x && b < 63)
 // only decides how much is saved.  Whether it pays is read off a sample of the partially sorted array (its head holds a
 // random subset of the k-mers with all their copies); with little duplication the keys finish the sort as before.
 static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bool both, u64* buf_a, u64* buf_b, uint64_t cap_keys,
-                        u64* out_k, u32* out_c, uint64_t cap, zk_kmerize_stats* st, uint64_t* n_out) {
+                        u64* out_k, u32* out_c, uint64_t cap, zk_kmerize_stats* st, uint64_t* n_out, bool canonical_only = false) {
     StreamSrc src{stream, n_bytes, K, both ? ZK_KEYS_BOTH : ZK_KEYS_CANONICAL, 0};
     // low bits to sort before looking for runs: 2^b >= 8 x keys, a whole number of passes, and at least one pass left over
     int collapse_bit = 0;
@@ -186,6 +232,14 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     if (!in_aux) ZK_TRY(rle(c, sorted, n, sorted, cnt, n, &uc));     // in place: sorted[0..uc) = distinct canonical k-mers
     st->n_canonical = uc;
     if (uc == 0) return ZK_OK;
+    if (canonical_only) {
+        // the caller wants the counted canonical list itself (multi-GPU: it is exchanged before the strands are rebuilt)
+        if (uc > cap) return fail(c, ZK_ENOSPC, "output holds %llu entries, the batch has %llu distinct canonical k-mers", (unsigned long long)cap, (unsigned long long)uc);
+        ZK_HIP(c, hipMemcpyAsync(out_k, sorted, 8 * uc, hipMemcpyDeviceToDevice, c->stream));
+        ZK_HIP(c, hipMemcpyAsync(out_c, cnt, 4 * uc, hipMemcpyDeviceToDevice, c->stream));
+        *n_out = uc;
+        return ZK_OK;
+    }
     const uint64_t a8 = (8 * uc + 255) & ~255ull, a4 = (4 * uc + 255) & ~255ull;
     u64 *rk, *rk2; u32 *rv, *rv2;
     if (in_aux) {
@@ -198,29 +252,7 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
         rk = (u64*)aux; rk2 = (u64*)(aux + a8);
         rv = (u32*)(aux + 2 * a8); rv2 = (u32*)(aux + 2 * a8 + a4);
     }
-    u64* sk; u32* sv;
-    if (2 * K >= MIRROR_GROUP_BITS + 8 && uc >= (1ull << 16)) {
-        // The list (c, n) is sorted by c, so the k-mers that share their first 9 bases are contiguous -- and those are
-        // exactly the mirrored keys rc(c) that share their LAST 9 bases, i.e. their low 18 bits.  The first two passes of
-        // an LSD sort of the mirrored keys would only move these 2^18 groups around whole; one copy does it: group
-        // boundaries by binary search, group order = order of the reversed-complemented prefix, then only the bits
-        // above 18 are sorted.
-        u64 *start, *dest;
-        ZK_TRY(arena_alloc(c, sizeof(u64) * ((1u << MIRROR_GROUP_BITS) + 1), (void**)&start));
-        ZK_TRY(arena_alloc(c, sizeof(u64) * (1u << MIRROR_GROUP_BITS), (void**)&dest));
-        prof_begin(c, ZK_PROF_MIRROR, 24 * uc);
-        hipLaunchKernelGGL(mirror_bounds_kernel, dim3(((1u << MIRROR_GROUP_BITS) + 256) / 256), dim3(256), 0, c->stream, sorted, (u64)uc, K, start);
-        hipLaunchKernelGGL(mirror_sizes_kernel, dim3((1u << MIRROR_GROUP_BITS) / 256), dim3(256), 0, c->stream, start, dest);
-        hipLaunchKernelGGL(mirror_scan_kernel, dim3(1), dim3(1024), 0, c->stream, dest);
-        hipLaunchKernelGGL(mirror_copy_kernel, dim3(ew_grid(c, uc)), dim3(256), 0, c->stream, sorted, cnt, (u64)uc, K, start, dest, rk, rv);
-        prof_end(c);
-        ZK_HIP(c, hipGetLastError());
-        ZK_TRY(sort_pairs_upper(c, rk, rk2, rv, rv2, uc, 2 * K, MIRROR_GROUP_BITS, &sk, &sv));
-    } else {
-        // small inputs / short k-mers: the histogram and the first pass of the sort read (c, n) and reverse-complement on load
-        ZK_TRY(sort_pairs_mirrored(c, sorted, cnt, rk, rk2, rv, rv2, uc, K, &sk, &sv));
-    }
-    return union_sum(c, sorted, cnt, uc, sk, sv, uc, out_k, out_c, 32, cap, n_out, nullptr);
+    return mirror_union(c, sorted, cnt, uc, K, rk, rk2, rv, rv2, out_k, out_c, cap, n_out);
 }
 
 // The short path: sort only the top T bits of the canonical keys (T ~ log2(n) + 3, a whole number
@@ -284,6 +316,9 @@ int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, dou
     if (K < 1 || K > 32) return fail(c, ZK_EINVAL, "K must be in 1..32 (got %d)", K);
     if (n_bytes == 0) return ZK_OK;
     const bool both = (flags & ZK_KMERIZE_BOTH) != 0;
+    const bool canonical_only = (flags & ZK_KMERIZE_CANONICAL_ONLY) != 0;
+    if (canonical_only && (both || (flags & ZK_KMERIZE_SUBSAMPLE)))
+        return fail(c, ZK_EINVAL, "ZK_KMERIZE_CANONICAL_ONLY cannot be combined with ZK_KMERIZE_BOTH or ZK_KMERIZE_SUBSAMPLE");
     const uint64_t cap_keys = both ? 2 * n_bytes : n_bytes;   // one window per stream byte at most
     arena_reset(c);
     const uint64_t slack = (9 << 20) + cap_keys / 16;          // histograms, merge-path partitions, the mirror group tables (4 MB)
@@ -294,7 +329,7 @@ int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, dou
 
     uint64_t n_out = 0;
     int rc = 1;
-    if (!both && c->short_sort) {
+    if (!both && c->short_sort && !canonical_only) {
         const int rb = sort_rbits(c);
         const int T = rb * ((ilog2_ceil(n_bytes) + 3 + rb - 1) / rb);
         if (T < 2 * K) {
@@ -303,7 +338,7 @@ int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, dou
             if (rc == 1) st->n_canonical = 0;      // side list overflowed: do it the long way
         }
     }
-    if (rc == 1) ZK_TRY(kmerize_full(c, stream, n_bytes, K, both, buf_a, buf_b, cap_keys, out_k, out_c, cap, st, &n_out));
+    if (rc == 1) ZK_TRY(kmerize_full(c, stream, n_bytes, K, both, buf_a, buf_b, cap_keys, out_k, out_c, cap, st, &n_out, canonical_only));
     if (flags & ZK_KMERIZE_SUBSAMPLE) {
         uint64_t kept = 0;
         ZK_TRY(subsample_pairs(c, out_k, out_c, n_out, seed, p, &kept));

@@ -157,6 +157,13 @@ class KmerTable:
             self.p, self.seed = subsample
             baits = None              # `if d is not None: ... elif B is not None:` (kmerize.py:494-520): -D wins over -C
         self.baits = baits            # DeviceArray of sorted both-strand bait k-mers, or None
+        # Without -D the batches are counted as CANONICAL lists (c = min(x, rc x), one entry per distinct window; half the
+        # size of the both-strand table), merged as such, and the strands are rebuilt ONCE at the end (zk_mirror_expand):
+        # a batch skips a fifth of its work, the merges move half the bytes.  -D is a predicate on the k-mers of both strands
+        # (x and rc x are hashed independently, kmerize.py:495-503), so it keeps the literal both-strand tables.
+        self.canonical = subsample is None
+        if self.canonical:
+            self.flags |= native.KMERIZE_CANONICAL_ONLY
         self.slab, self.scratch = slabs_for(ctx)
         self.stack = []               # [(offset, n, level)] bottom to top, contiguous from offset 0
         self.top = 0
@@ -201,6 +208,8 @@ class KmerTable:
         if d.n == 0:
             return
         bound = int(bound) if bound else 2 * d.n
+        if self.canonical:
+            bound = (bound + 1) // 2          # one entry per window, not two
         est = bound if self.ratio is None else min(bound, int(d.n * self.ratio * 1.2) + 65536)
         acgt = None
         n_in = d.n
@@ -260,15 +269,31 @@ class KmerTable:
         k, c, h = self.device_result()
         return k.to_host(), c.to_host(), h
 
-    def device_result(self):
-        """(kmers, counts) as device arrays (views of the table slab, valid until the slab is used again) + hist."""
+    def _folded(self):
+        """the one table left after merging whatever waits on the stack: (kmers, counts) views of the table slab"""
         if not self.stack:
             e = self.ctx.empty(0, np.uint64)
-            return e.view(0), self.ctx.empty(0, np.uint32).view(0), {}
+            return e.view(0), self.ctx.empty(0, np.uint32).view(0)
         while len(self.stack) > 1:
             self._merge_top()
         off, n, _ = self.stack[0]
-        k, c = self.slab.k.view(n, off), self.slab.c.view(n, off)
+        return self.slab.k.view(n, off), self.slab.c.view(n, off)
+
+    def canonical_result(self):
+        """(canonical k-mers, counts) before the strands are rebuilt -- what the multi-GPU path exchanges.  Only in
+        canonical mode (no -D)."""
+        assert self.canonical
+        return self._folded()
+
+    def device_result(self):
+        """(kmers, counts) of both strands as device arrays (views of the table memory, valid until it is used again) + hist."""
+        k, c = self._folded()
+        if self.canonical and k.n:
+            self.scratch.ensure(2 * k.n)
+            with _Phase(self.ctx, "mirror_expand %d" % k.n):
+                k, c = self.ctx.mirror_expand(k, c, self.K, out=(self.scratch.k.view(2 * k.n), self.scratch.c.view(2 * k.n)))
+        if k.n == 0:
+            return k, c, {}
         with _Phase(self.ctx, "hist"):
             h = self.ctx.hist(c)
         return k, c, h

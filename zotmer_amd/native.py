@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ZOTK_LIB") or os.path.join(_HERE, "libzotk.so")
 
 ZK_OK, ZK_EINVAL, ZK_ENOMEM, ZK_EHIP, ZK_ENOSPC, ZK_EOVERFLOW, ZK_EINTERNAL, ZK_ERANGE = 0, -1, -2, -3, -4, -5, -6, -7
-KMERIZE_CANONICAL, KMERIZE_BOTH, KMERIZE_SUBSAMPLE = 0, 1, 2
+KMERIZE_CANONICAL, KMERIZE_BOTH, KMERIZE_SUBSAMPLE, KMERIZE_CANONICAL_ONLY = 0, 1, 2, 4
 
 _ERRNAMES = {-1: "ZK_EINVAL", -2: "ZK_ENOMEM", -3: "ZK_EHIP", -4: "ZK_ENOSPC", -5: "ZK_EOVERFLOW",
              -6: "ZK_EINTERNAL", -7: "ZK_ERANGE"}
@@ -71,6 +71,7 @@ SIGNATURES = {
     "zk_rle": (_i, [_vp, _vp, _u64, _vp, _vp, _u64, _pu64]),
     "zk_sort_count": (_i, [_vp, _vp, _u64, _i, _vp, _vp, _u64, _pu64]),
     "zk_kmerize": (_i, [_vp, _vp, _u64, _i, _i, _d, _u64, _vp, _vp, _u64, C.POINTER(KmerizeStats)]),
+    "zk_mirror_expand": (_i, [_vp, _vp, _vp, _u64, _i, _vp, _vp, _u64, _pu64]),
     "zk_hist": (_i, [_vp, _vp, _i, _u64, _pu64, _pu64, _u64, _pu64]),
     "zk_widen_counts": (_i, [_vp, _vp, _vp, _u64]),
     "zk_union_sum": (_i, [_vp, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _i, _u64, _pu64, _pu64]),
@@ -399,6 +400,16 @@ class Context:
         st = KmerizeStats()
         self._check(self.lib.zk_kmerize(self.h, stream.ptr, stream.n, K, flags, float(p), int(seed), ok.ptr, oc.ptr, cap, C.byref(st)))
         return ok.view(st.n_unique), oc.view(st.n_unique), st
+
+    def mirror_expand(self, ck, cc, K, out=None):
+        """counted canonical list (zk_kmerize with KMERIZE_CANONICAL_ONLY) -> (kmers, counts) of both strands"""
+        if out is None:
+            ok, oc = self.empty(2 * ck.n, np.uint64), self.empty(2 * ck.n, np.uint32)
+        else:
+            ok, oc = out
+        n = C.c_uint64(0)
+        self._check(self.lib.zk_mirror_expand(self.h, ck.ptr, cc.ptr, ck.n, int(K), ok.ptr, oc.ptr, min(ok.n, oc.n), C.byref(n)))
+        return ok.view(n.value), oc.view(n.value)
 
     def hist(self, counts):
         bits = counts.dtype.itemsize * 8

@@ -252,6 +252,16 @@ class GpuOps:
         k, c, acgt = self.ctx.merge_n(parts, out=(self._mk, self._mc))
         return (k, c, acgt) if want_acgt else (k, c)
 
+    def mirror_expand(self, k, c, K):
+        """the owned canonical piece -> (kmers, counts) of both strands (zk_mirror_expand; output buffers kept between steps)"""
+        if k.n == 0:
+            return k, c
+        if getattr(self, "_xk", None) is None or self._xk.n < 2 * k.n:
+            self._xk = self._xc = None
+            self._xk = self.ctx.empty(2 * k.n + k.n // 8, np.uint64)
+            self._xc = self.ctx.empty(2 * k.n + k.n // 8, np.uint32)
+        return self.ctx.mirror_expand(k, c, K, out=(self._xk, self._xc))
+
     def dedupe(self, keys_t, n, shift=0):
         """Measure.prep (commands/dist.py:43-49): x >> shift, adjacent duplicates dropped -> (tensor, n)"""
         out_t = self.empty(n, torch.int64)
@@ -298,6 +308,7 @@ class Exchange:
         self.ops = ops if ops is not None else GpuOps(ctx)
         self.cuts = splitters(K, self.world)      # static cuts until balanced_cuts() is called
         self._rk = self._rc = None                 # receive buffers, kept between steps (grown on demand)
+        self.by_canonical = False                  # pieces own k-mers by their CANONICAL form (kmerize_finish): not value ranges
 
     # back-compatible knob used by the tests to force several rounds per all-to-all
     @property
@@ -425,6 +436,18 @@ class Exchange:
         return pos[self.rank], pos[self.rank + 1]
 
     # ---- product functions ----------------------------------------------------------------------------
+    def kmerize_finish(self, keys_t, counts_t, n):
+        """`zot kmerize` over the ranks: keys_t / counts_t = this rank's counted CANONICAL list (zk_kmerize with
+        ZK_KMERIZE_CANONICAL_ONLY: half the size of the both-strand table).  The canonical lists are cut by owner, exchanged
+        and union-summed; each rank then rebuilds both strands of the k-mers whose canonical form it owns
+        (zk_mirror_expand).  The owned pieces partition the global table (x and rc x always live on the same rank) but are
+        not value ranges: the writer merges them (gather_to_root).  Returns (kmers, counts) of both strands."""
+        self.by_canonical = True
+        if self.owner == "range":
+            self.balanced_cuts([(keys_t, n)])
+        k, c = self.exchange_and_merge(keys_t, counts_t, n)
+        return self.ops.mirror_expand(k, c, self.K)
+
     def merge_sets(self, keys_t, counts_t, n):
         """`zot merge` over the ranks (commands/merge.py:127-163,165-253).  keys_t / counts_t (int64, 64-bit counts): the
         k-way merge of the sets THIS rank loaded (sets r, r+world, ...).  Returns dict(k, c, acgt, hist, n_global):
@@ -492,7 +515,7 @@ class Exchange:
         if self.rank != root:
             return None, None
         segs = [(roff[r], recv[r]) for r in range(W)]
-        if self.owner == "hash":
+        if self.owner == "hash" or self.by_canonical:
             return ops.merge_segments(rk, rc, segs)
         return ops.merge_segments(rk, rc, [(0, total)])
 
