@@ -2,6 +2,11 @@
 Host-side closed forms behind `zot jaccard -p`: the regularised incomplete beta function by its
 series, and its quantiles by bisection.  Plain double arithmetic, evaluated in the same order as the
 reference so the printed digits agree (zotmer/library/stats.py:36-129, zotmer/commands/jaccard.py:56-88).
+
+This file is a RESTATEMENT, by necessity close to its source: `log_ix` and `quant_beta` follow `logIx` and `quantBeta`
+(jaccard.py:56-84) term by term, because `zot jaccard` prints the results with `%f` and the last digits depend on the
+order of the floating-point operations (the series' term recurrence, the bisection's midpoint and stopping rule).  It is
+host-side formatting logic, not part of the accelerated path; parity is pinned by tests/golden/f3_jaccard.json.
 """
 import math
 
