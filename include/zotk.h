@@ -118,6 +118,10 @@ int zk_subsample(zk_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint64_t seed
 int zk_capture_filter(zk_ctx* ctx, const uint8_t* d_stream, uint64_t n_bytes, int K, const uint64_t* d_baits, uint64_t n_baits,
                       uint8_t* d_out, uint64_t* n_reads, uint64_t* n_kept);
 
+/* basics.can (library/basics.py:231-250; used by `zot vars`): per k-mer, whichever of x and rc(x) has the smaller
+ * murmer(., 17) -- x on a tie.  Element-wise, asynchronous; d_out may equal d_kmers. */
+int zk_can(zk_ctx* ctx, int K, const uint64_t* d_kmers, uint64_t n, uint64_t* d_out);
+
 /* ---- K3/K4: sort and count ------------------------------------------------------------------ */
 
 /* misc.radix_sort(key_bits, xs) (library/misc.py:400-424): ascending, in place. */

@@ -42,6 +42,19 @@ def test_synth_device_matches_numpy(ctx, kw):
         assert np.array_equal(got, want)
 
 
+def test_can_golden_and_oracle(ctx):
+    """basics.can on the device against the reference's own values (tests/golden/primitives.json) and the oracle"""
+    P = G.load_json("primitives")
+    for K in sorted({c[0] for c in P["can"]}):
+        rows = [c for c in P["can"] if c[0] == K]
+        got = ctx.can(K, ctx.upload(np.array([c[1] for c in rows], dtype=np.uint64))).to_host()
+        assert [int(v) for v in got] == [c[2] for c in rows]
+    rng = np.random.default_rng(9)
+    for K in (1, 16, 25, 31, 32):
+        x = rng.integers(0, 1 << 63, size=5000, dtype=np.uint64) & np.uint64((1 << (2 * K)) - 1 if K < 32 else (1 << 64) - 1)
+        assert [int(v) for v in ctx.can(K, ctx.upload(x)).to_host()] == [zo.can(K, int(v)) for v in x]
+
+
 # ---- K1 encode --------------------------------------------------------------------------------------
 
 def test_encode_golden_kmersList(ctx):

@@ -200,11 +200,30 @@ __global__ void synth_counts_kernel(u64 seed, const u64* __restrict__ keys, u64 
     }
 }
 
+// basics.can (zotmer/library/basics.py:231-250): of x and rc(x), the one with the smaller murmer hash (seed 17), x on a tie
+__global__ void can_kernel(const u64* __restrict__ in, u64 n, int K, u64* __restrict__ out) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 x = in[i], xb = revcomp(K, x);
+        out[i] = (murmer(x, 17) <= murmer(xb, 17)) ? x : xb;
+    }
+}
+
 }  // namespace zk
 
 using namespace zk;
 
 extern "C" {
+
+int zk_can(zk_ctx* c, int K, const uint64_t* d_kmers, uint64_t n, uint64_t* d_out) {
+    if (!c) return ZK_EINVAL;
+    enter(c);
+    if (K < 1 || K > 32 || (n && (!d_kmers || !d_out))) return fail(c, ZK_EINVAL, "zk_can: bad argument");
+    if (n == 0) return ZK_OK;
+    u64 g = div_up(n, 256 * 8), mx = (u64)c->num_cus * 16;
+    hipLaunchKernelGGL(can_kernel, dim3((u32)(g < mx ? g : mx)), dim3(256), 0, c->stream, (const u64*)d_kmers, (u64)n, K, (u64*)d_out);
+    ZK_HIP(c, hipGetLastError());
+    return ZK_OK;
+}
 
 int zk_hash_partition(zk_ctx* c, const uint64_t* d_kmers, const void* d_counts, int count_bits, uint64_t n, int world, uint64_t seed,
                       uint64_t* d_ok, void* d_oc, uint64_t* offsets) {

@@ -66,6 +66,7 @@ SIGNATURES = {
     "zk_encode": (_i, [_vp, _vp, _u64, _i, _i, _vp, _u64, _pu64, _pu64]),
     "zk_capture_filter": (_i, [_vp, _vp, _u64, _i, _vp, _u64, _vp, _pu64, _pu64]),
     "zk_subsample": (_i, [_vp, _vp, _u64, _u64, _d, _vp, _u64, _pu64]),
+    "zk_can": (_i, [_vp, _i, _vp, _u64, _vp]),
     "zk_sort_keys": (_i, [_vp, _vp, _u64, _i]),
     "zk_sort_pairs": (_i, [_vp, _vp, _vp, _u64, _i]),
     "zk_rle": (_i, [_vp, _vp, _u64, _vp, _vp, _u64, _pu64]),
@@ -365,6 +366,13 @@ class Context:
         n = C.c_uint64(0)
         self._check(self.lib.zk_subsample(self.h, kmers.ptr, kmers.n, int(seed), float(p), out.ptr, kmers.n, C.byref(n)))
         return out.view(n.value)
+
+    def can(self, K, kmers):
+        """basics.can per element: the strand with the smaller murmer(., 17)"""
+        out = self.empty(kmers.n, np.uint64)
+        self._check(self.lib.zk_can(self.h, int(K), kmers.ptr, kmers.n, out.ptr))
+        self.sync()
+        return out
 
     def sort_keys(self, keys, key_bits):
         self._check(self.lib.zk_sort_keys(self.h, keys.ptr, keys.n, key_bits))
