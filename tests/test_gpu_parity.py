@@ -307,18 +307,21 @@ def test_kmerize_early_collapse_paths_agree(ctx, K):
     tail = "".join(rng.choice(list("ACGT"), size=40))
     shared = [h + tail for h in ("A", "C", "G", "T", "AC", "GT", "TTA", "CAG")] * 400
     rng.shuffle(shared)
-    for name, reads in (("deep", deep), ("flat", flat), ("shared_low_bits", shared + deep[:500]), ("mixed", deep[:2000] + flat[:2000] + shared)):
+    # counts beyond the spare bits of a packed (k-mer << s | count) word (K = 25: 14 bits): the packed forms must step aside
+    heavy = deep[:1500] + ["A" * 150] * 400 + ["AC" * 75] * 300
+    for name, reads in (("deep", deep), ("flat", flat), ("shared_low_bits", shared + deep[:500]), ("mixed", deep[:2000] + flat[:2000] + shared),
+                        ("heavy_counts", heavy)):
         want = zo.kmerize(K, reads)
         d = ctx.upload_stream(stream_of(reads))
         try:
-            for on in (1, 0):
-                ctx.tune(early_collapse=on)
+            for on, packed in ((1, 1), (1, 0), (0, 1), (0, 0)):
+                ctx.tune(early_collapse=on, packed_pairs=packed)
                 k, c, st = ctx.kmerize(d, K)
-                assert np.array_equal(k.to_host(), want["kmers"]), (name, on)
-                assert np.array_equal(c.to_host(), want["counts"]), (name, on)
+                assert np.array_equal(k.to_host(), want["kmers"]), (name, on, packed)
+                assert np.array_equal(c.to_host(), want["counts"]), (name, on, packed)
                 assert list(st.acgt) == want["acgt"] and st.n_unique == len(want["kmers"])
         finally:
-            ctx.tune(early_collapse=1)
+            ctx.tune(early_collapse=1, packed_pairs=1)
 
 
 @pytest.mark.parametrize("K", [4, 12, 24, 25, 31, 32])

@@ -17,6 +17,8 @@ struct zk_ctx {
     int sort_variant = 3;      // radix-sort geometry for key arrays (zk_tune); 3 = 512 threads x 16 keys, 9-bit digits
     int short_sort = 0;        // zk_kmerize: 1 = sort only the top ~log2(n)+3 bits and finish in the mirror stage (opt-in:
                                // pays off on uncorrelated reads only)
+    int packed_pairs = 1;      // (k-mer, count) pairs travel as ONE word (k-mer << s | count) through the key kernel when the counts fit the
+                               // spare bits above 2K (pipeline.hip); zk_tune, tests
     int early_collapse = 1;    // zk_kmerize (canonical): run-length count after the low-bit passes, finish the sort on pairs (pipeline.hip)
     int side_div = 8;          // ... side list capacity = n / side_div (tests shrink it to force the fallback)
     int pairs_variant = 2;     // ... for (key, u32) pairs
@@ -131,8 +133,10 @@ int capture_filter(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, const u
 int rle_prefix(zk_ctx* c, const u64* sorted, uint64_t n, int pshift, u64* uniq, u32* counts, uint64_t cap, uint64_t* n_main,
                u64* side_k, u32* side_c, uint64_t side_cap, uint64_t* n_side);
 int sample_heads(zk_ctx* c, const u64* keys, uint64_t n, uint64_t* sampled, uint64_t* heads);   // adjacent-distinct count of a prefix
-int reduce_by_key(zk_ctx* c, const u64* sorted, const u32* w, uint64_t n, u64* uniq, u32* sums, uint64_t cap, uint64_t* n_out);
-int rle(zk_ctx* c, const u64* sorted, uint64_t n, u64* uniq, u32* counts, uint64_t cap, uint64_t* n_unique);
+int reduce_by_key(zk_ctx* c, const u64* sorted, const u32* w, uint64_t n, u64* uniq, u32* sums, uint64_t cap, uint64_t* n_out, int pack = 0,
+                  uint64_t* max_sum = nullptr);
+int rle(zk_ctx* c, const u64* sorted, uint64_t n, u64* uniq, u32* counts, uint64_t cap, uint64_t* n_unique, int pack = 0,
+        bool* overflow = nullptr);
 int count_hist(zk_ctx* c, const void* counts, int count_bits, uint64_t n, uint64_t* vals, uint64_t* freq,
                uint64_t cap_bins, uint64_t* n_bins);
 // codec.hip
@@ -150,6 +154,9 @@ int checksum_any(zk_ctx* c, const u64* keys, const void* cnts, int count_bits, u
 // setops.hip
 int union_sum(zk_ctx* c, const u64* A, const void* cA, u64 nA, const u64* B, const void* cB, u64 nB, u64* ok, void* oc,
               int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);
+// 32-bit counts; the B side is ONE array of (key << pack) | count words
+int union_sum_packed_b(zk_ctx* c, const u64* A, const u32* cA, u64 nA, const u64* Bp, u64 nB, int pack, u64* ok, u32* oc, uint64_t cap,
+                       uint64_t* n_out);
 int column_sum(zk_ctx* c, const u64* rows, uint64_t n_rows, int cols, u64* out);   // out[c] = sum of rows[r][c]
 int project(zk_ctx* c, const u64* ref, u64 n_ref, const u64* B, const u64* cB, u64 nB, u64* ok, u64* oc, uint64_t cap, uint64_t* n_out);
 int intersect_count(zk_ctx* c, const u64* A, u64 nA, const u64* B, u64 nB, uint64_t abc[3]);

@@ -78,15 +78,16 @@ __global__ __launch_bounds__(1024) void mirror_scan_kernel(u64* __restrict__ siz
     }
 }
 
+// pack > 0: r[pos] = (rc(c) << pack) | n -- one word per pair (v is not written); the caller has checked that every n fits
 __global__ void mirror_copy_kernel(const u64* __restrict__ c, const u32* __restrict__ n, u64 m, int K, const u64* __restrict__ start,
-                                   const u64* __restrict__ dest, u64* __restrict__ r, u32* __restrict__ v) {
+                                   const u64* __restrict__ dest, u64* __restrict__ r, u32* __restrict__ v, int pack) {
     const int sh = 2 * K - MIRROR_GROUP_BITS;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (u64)gridDim.x * blockDim.x) {
         const u64 x = c[i];
         const u32 g = (u32)(x >> sh);
         const u64 pos = dest[(u32)revcomp(MIRROR_GROUP_BASES, (u64)g)] + (i - start[g]);      // dest is indexed by v = rc9(g)
-        r[pos] = revcomp(K, x);
-        v[pos] = n[i];
+        if (pack) r[pos] = (revcomp(K, x) << pack) | (u64)n[i];
+        else { r[pos] = revcomp(K, x); v[pos] = n[i]; }
     }
 }
 
@@ -120,13 +121,44 @@ __global__ void side_expand_kernel(const u64* __restrict__ k, const u32* __restr
 
 static int ilog2_ceil(uint64_t x) { int b = 0; while ((1ull << b) < x && b < 63) b++; return b; }
 
+// Spare bits above a 2K-bit k-mer in a 64-bit word: room for the count when pairs travel as one word.  Worth it from 10
+// bits up (K <= 27); 0 = keep key and count apart.
+static int pack_bits_for(int K) {
+    const int spare = 64 - 2 * K;
+    return spare >= 10 ? (spare > 31 ? 31 : spare) : 0;
+}
+
+__global__ void max_u32_kernel(const u32* __restrict__ v, u64 n, u32* out) {
+    u32 m = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) m = v[i] > m ? v[i] : m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const u32 t = (u32)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+static int max_u32(zk_ctx* c, const u32* v, uint64_t n, uint64_t* out) {
+    u32* d = (u32*)(c->d_scalars + 26);
+    ZK_HIP(c, hipMemsetAsync(d, 0, sizeof(u64), c->stream));
+    if (n) {
+        hipLaunchKernelGGL(max_u32_kernel, dim3(ew_grid(c, n)), dim3(256), 0, c->stream, v, (u64)n, d);
+        ZK_HIP(c, hipGetLastError());
+    }
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 26, c->d_scalars + 26, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    *out = c->h_scalars[26] & 0xffffffffull;
+    return ZK_OK;
+}
+
 // Both strands from the counted canonical list (c, n), c ascending: the pairs (rc c, n) are sorted by key and union-summed
 // with (c, n); a palindrome (c == rc c, even K) meets itself there and gets n + n -- two emissions per window, as the
 // reference has them (commands/kmerize.py:490, library/reads.py:113-114).  rk / rk2 (8 bytes per entry) and rv / rv2 (4) are
 // work buffers; start / dest tables come from the arena.
+// pack > 0 (the caller knows every count is below 2^pack, and 2K + pack <= 64): the mirrored pairs travel as single words
+// (rc c << pack | n) through the key kernel -- 16 bytes per pair and pass instead of 24 -- and the union reads them so.
 static int mirror_union(zk_ctx* c, const u64* sorted, const u32* cnt, uint64_t uc, int K, u64* rk, u64* rk2, u32* rv, u32* rv2,
-                        u64* out_k, u32* out_c, uint64_t cap, uint64_t* n_out) {
+                        u64* out_k, u32* out_c, uint64_t cap, uint64_t* n_out, int pack = 0) {
     u64* sk; u32* sv;
+    if (!(2 * K >= MIRROR_GROUP_BITS + 8 && uc >= (1ull << 16))) pack = 0;
     if (2 * K >= MIRROR_GROUP_BITS + 8 && uc >= (1ull << 16)) {
         // The list (c, n) is sorted by c, so the k-mers that share their first 9 bases are contiguous -- and those are
         // exactly the mirrored keys rc(c) that share their LAST 9 bases, i.e. their low 18 bits.  The first two passes of
@@ -140,9 +172,13 @@ static int mirror_union(zk_ctx* c, const u64* sorted, const u32* cnt, uint64_t u
         hipLaunchKernelGGL(mirror_bounds_kernel, dim3(((1u << MIRROR_GROUP_BITS) + 256) / 256), dim3(256), 0, c->stream, sorted, (u64)uc, K, start);
         hipLaunchKernelGGL(mirror_sizes_kernel, dim3((1u << MIRROR_GROUP_BITS) / 256), dim3(256), 0, c->stream, start, dest);
         hipLaunchKernelGGL(mirror_scan_kernel, dim3(1), dim3(1024), 0, c->stream, dest);
-        hipLaunchKernelGGL(mirror_copy_kernel, dim3(ew_grid(c, uc)), dim3(256), 0, c->stream, sorted, cnt, (u64)uc, K, start, dest, rk, rv);
+        hipLaunchKernelGGL(mirror_copy_kernel, dim3(ew_grid(c, uc)), dim3(256), 0, c->stream, sorted, cnt, (u64)uc, K, start, dest, rk, rv, pack);
         prof_end(c);
         ZK_HIP(c, hipGetLastError());
+        if (pack) {
+            ZK_TRY(sort_keys_upper(c, rk, rk2, uc, 2 * K + pack, MIRROR_GROUP_BITS + pack, &sk));
+            return union_sum_packed_b(c, sorted, cnt, uc, sk, uc, pack, out_k, out_c, cap, n_out);
+        }
         ZK_TRY(sort_pairs_upper(c, rk, rk2, rv, rv2, uc, 2 * K, MIRROR_GROUP_BITS, &sk, &sv));
     } else {
         // small inputs / short k-mers: the histogram and the first pass of the sort read (c, n) and reverse-complement on load
@@ -162,7 +198,13 @@ int mirror_expand(zk_ctx* c, const u64* ck, const u32* cc, uint64_t n, int K, u6
     ZK_TRY(arena_require(c, need, need));
     char* w;
     ZK_TRY(arena_alloc(c, 2 * a8 + 2 * a4, (void**)&w));
-    ZK_TRY(mirror_union(c, ck, cc, n, K, (u64*)w, (u64*)(w + a8), (u32*)(w + 2 * a8), (u32*)(w + 2 * a8 + a4), out_k, out_c, cap, n_out));
+    int pack = 0;
+    if (c->packed_pairs && pack_bits_for(K)) {
+        uint64_t mx = 0;
+        ZK_TRY(max_u32(c, cc, n, &mx));
+        if (mx < (1ull << pack_bits_for(K))) pack = pack_bits_for(K);
+    }
+    ZK_TRY(mirror_union(c, ck, cc, n, K, (u64*)w, (u64*)(w + a8), (u32*)(w + 2 * a8), (u32*)(w + 2 * a8 + a4), out_k, out_c, cap, n_out, pack));
     return check_device_error(c);
 }
 
@@ -201,10 +243,37 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     u32* cnt = (u32*)other;
     uint64_t uc = 0;
     bool in_aux = false;          // the counted list lives in the aux region (collapse path): both sort buffers are free
+    uint64_t max_count = 0;       // largest count of the list, when it came for free (packed reduce)
+    bool have_max = false;
     if (collapse_bit && n) {
         uint64_t m = 0, heads = 0;
         ZK_TRY(sample_heads(c, sorted, n, &m, &heads));
-        if ((double)heads <= 0.6 * (double)m) {
+        const int pk = c->packed_pairs ? pack_bits_for(K) : 0;
+        bool done_packed = false;
+        if ((double)heads <= 0.6 * (double)m && pk) {
+            // The runs as single words (key << pk | length): written beside the keys (not over them: should a run be longer
+            // than 2^pk - 1 the keys are still there and the pair path below takes over), the upper bits sorted by the key
+            // kernel, the split runs summed straight from the words.
+            const uint64_t cap1 = (8 * cap_keys) / 8;                     // `other` holds cap_keys words
+            uint64_t u1 = 0;
+            bool ovf = false;
+            int rc1 = rle(c, sorted, n, other, nullptr, cap1, &u1, pk, &ovf);
+            if (rc1 != ZK_OK && rc1 != ZK_ENOSPC) return rc1;
+            if (rc1 == ZK_OK && !ovf) {
+                u64* res = nullptr;
+                ZK_TRY(sort_keys_upper(c, other, sorted, u1, 2 * K + pk, collapse_bit + pk, &res));
+                const uint64_t a8 = (8 * u1 + 255) & ~255ull, a4 = (4 * u1 + 255) & ~255ull;
+                char* aux;
+                ZK_TRY(aux_require(c, a8 + a4, &aux));
+                ZK_TRY(reduce_by_key(c, res, nullptr, u1, (u64*)aux, (u32*)(aux + a8), u1, &uc, pk, &max_count));
+                sorted = (u64*)aux; cnt = (u32*)(aux + a8);
+                in_aux = true;
+                done_packed = true;
+                have_max = true;
+            }
+        }
+        if (done_packed) {
+        } else if ((double)heads <= 0.6 * (double)m) {
             uint64_t u1 = 0;
             ZK_TRY(rle(c, sorted, n, sorted, cnt, n, &u1));          // in place: runs of adjacent equal keys
             const uint64_t a8 = (8 * u1 + 255) & ~255ull, a4 = (4 * u1 + 255) & ~255ull;
@@ -252,7 +321,12 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
         rk = (u64*)aux; rk2 = (u64*)(aux + a8);
         rv = (u32*)(aux + 2 * a8); rv2 = (u32*)(aux + 2 * a8 + a4);
     }
-    return mirror_union(c, sorted, cnt, uc, K, rk, rk2, rv, rv2, out_k, out_c, cap, n_out);
+    int pack = 0;
+    if (c->packed_pairs && pack_bits_for(K)) {
+        if (!have_max) ZK_TRY(max_u32(c, cnt, uc, &max_count));
+        if (max_count < (1ull << pack_bits_for(K))) pack = pack_bits_for(K);
+    }
+    return mirror_union(c, sorted, cnt, uc, K, rk, rk2, rv, rv2, out_k, out_c, cap, n_out, pack);
 }
 
 // The short path: sort only the top T bits of the canonical keys (T ~ log2(n) + 3, a whole number

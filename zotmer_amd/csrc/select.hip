@@ -94,9 +94,14 @@ struct RleSmem {
 // the distance to the next set bit (same row, a later row of the wave, a later wave via LDS, or
 // the end of the tile), its output slot a popcount.  8192 keys per tile keep the tile rate -- and
 // with it the length of the look-back chains -- low.
+// pack > 0: uniq[j] holds (key << pack) | min(count, 2^pack - 1) -- key and count in ONE word, so that the passes which
+// finish the sort move 8 bytes per entry through the fast key kernel instead of 12 through the pair kernel.  Should a
+// count not fit, *ovf is set and the caller starts over without packing, so in this mode uniq must NOT alias keys (the
+// in-place form also relies on an overwritten neighbour keeping its value, which a packed word does not); counts may be
+// null.
 __global__ __launch_bounds__(RLE_BLOCK) void rle_kernel(const u64* keys, u64 n, u64* uniq,
                                                         u32* __restrict__ counts, u64 cap, u32* __restrict__ lead,
-                                                        SelState st) {
+                                                        SelState st, int pack, u32* ovf) {
     __shared__ RleSmem sm;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u32 tile = take_ticket(st.ticket, &sm.sel.ticket) - st.ticket_base;
@@ -156,8 +161,15 @@ __global__ __launch_bounds__(RLE_BLOCK) void rle_kernel(const u64* keys, u64 n, 
             else nxt = (nh[i] != RLE_NONE) ? wave_rel + nh[i] : next_wave;
             const u64 pos = q + popc_below(hm[i]);
             if (pos < cap) {
-                uniq[pos] = k[i];
-                counts[pos] = nxt - me;
+                const u32 len = nxt - me;
+                if (pack) {
+                    const u32 top = (1u << pack) - 1u;
+                    if (len > top) atomicOr(ovf, 1u);
+                    uniq[pos] = (k[i] << pack) | (u64)(len < top ? len : top);
+                } else {
+                    uniq[pos] = k[i];
+                }
+                if (counts) counts[pos] = len;
             }
         }
         q += (u32)__popcll(hm[i]);
@@ -369,9 +381,10 @@ struct RbkSmem {
     u32 lead;                 // sum of the weights of the leading elements that belong to the previous tile's run
 };
 
+// pack > 0: keys[] holds (key << pack) | weight and w is not read; maxsum (may be null) gets the largest sum written
 __global__ __launch_bounds__(RLE_BLOCK) void reduce_by_key_kernel(const u64* __restrict__ keys, const u32* __restrict__ w, u64 n,
                                                                   u64* __restrict__ uniq, u32* __restrict__ sums, u64 cap,
-                                                                  u32* __restrict__ lead, SelState st) {
+                                                                  u32* __restrict__ lead, SelState st, int pack, u32* maxsum) {
     __shared__ RbkSmem sm;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u32 tile = take_ticket(st.ticket, &sm.sel.ticket) - st.ticket_base;
@@ -386,7 +399,12 @@ __global__ __launch_bounds__(RLE_BLOCK) void reduce_by_key_kernel(const u64* __r
     for (int i = 0; i < RLE_ITEMS; i++) {
         const u64 idx = base + (u64)i * 64 + lane;
         k[i] = (idx < n) ? keys[idx] : 0ull;
-        wt[i] = (idx < n) ? w[idx] : 0u;
+        if (pack) {
+            wt[i] = (u32)(k[i] & ((1ull << pack) - 1ull));
+            k[i] >>= pack;
+        } else {
+            wt[i] = (idx < n) ? w[idx] : 0u;
+        }
     }
 #pragma unroll
     for (int i = 0; i < RLE_ITEMS; i++) {
@@ -396,7 +414,7 @@ __global__ __launch_bounds__(RLE_BLOCK) void reduce_by_key_kernel(const u64* __r
             const u64 last = __shfl(k[i - 1], 63, 64);
             if (lane == 0) prev = last;
         } else if (lane == 0) {
-            prev = (idx > 0 && idx < n) ? keys[idx - 1] : 0ull;
+            prev = (idx > 0 && idx < n) ? (keys[idx - 1] >> pack) : 0ull;
         }
         const bool head = (idx < n) && (idx == 0 || k[i] != prev);
         hm[i] = __ballot(head);
@@ -420,14 +438,21 @@ __global__ __launch_bounds__(RLE_BLOCK) void reduce_by_key_kernel(const u64* __r
     }
     __syncthreads();
     q = (u32)(wbase - tile_first);
+    u32 mx = 0;
 #pragma unroll
     for (int i = 0; i < RLE_ITEMS; i++) {
         if ((hm[i] >> lane) & 1ull) {
             const u32 r = q + popc_below(hm[i]);
             const u64 pos = tile_first + r;
             if (pos < cap) { uniq[pos] = k[i]; sums[pos] = sm.sum[r]; }
+            if (sm.sum[r] > mx) mx = sm.sum[r];
         }
         q += (u32)__popcll(hm[i]);
+    }
+    if (maxsum) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const u32 t = (u32)__shfl_xor((int)mx, o, 64); mx = t > mx ? t : mx; }
+        if (lane == 0 && mx) atomicMax(maxsum, mx);
     }
     if (threadIdx.x == 0) {
         lead[tile] = sm.lead;
@@ -436,7 +461,8 @@ __global__ __launch_bounds__(RLE_BLOCK) void reduce_by_key_kernel(const u64* __r
 }
 
 // sums[(first output slot of tile t) - 1] += lead[t]
-__global__ void reduce_fixup_kernel(const u32* __restrict__ lead, const u64* __restrict__ status, u32 tiles, u32* sums, u64 cap, u32* err) {
+__global__ void reduce_fixup_kernel(const u32* __restrict__ lead, const u64* __restrict__ status, u32 tiles, u32* sums, u64 cap, u32* err,
+                                    u32* maxsum) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0 || t >= tiles) return;
     const u32 l = lead[t];
@@ -445,27 +471,36 @@ __global__ void reduce_fixup_kernel(const u32* __restrict__ lead, const u64* __r
     if (excl == 0 || excl - 1 >= cap) return;
     const u32 old = atomicAdd(&sums[excl - 1], l);
     if (old + l < old) atomicOr(err, ZK_DERR_COUNT_OVERFLOW);
+    if (maxsum) atomicMax(maxsum, old + l);
 }
 
-int reduce_by_key(zk_ctx* c, const u64* sorted, const u32* w, uint64_t n, u64* uniq, u32* sums, uint64_t cap, uint64_t* n_out) {
+// pack > 0: `sorted` holds (key << pack) | weight, `w` is ignored.  max_sum (may be null): the largest sum written.
+int reduce_by_key(zk_ctx* c, const u64* sorted, const u32* w, uint64_t n, u64* uniq, u32* sums, uint64_t cap, uint64_t* n_out, int pack,
+                  uint64_t* max_sum) {
     *n_out = 0;
+    if (max_sum) *max_sum = 0;
     if (n == 0) return ZK_OK;
+    u32* d_max = max_sum ? (u32*)(c->d_scalars + 25) : nullptr;
+    if (d_max) ZK_HIP(c, hipMemsetAsync(d_max, 0, sizeof(u64), c->stream));
     SelState st;
     st.tiles = (u32)div_up(n, RLE_TILE);
     u32* lead;
     ZK_TRY(arena_alloc(c, sizeof(u32) * st.tiles, (void**)&lead));
     ZK_TRY(lookback_begin(c, st.tiles, st.tiles, &st.epoch, &st.ticket_base));
     st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9;
-    prof_begin(c, ZK_PROF_SELECT, 12 * n);
-    hipLaunchKernelGGL(reduce_by_key_kernel, dim3(st.tiles), dim3(RLE_BLOCK), 0, c->stream, sorted, w, (u64)n, uniq, sums, (u64)cap, lead, st);
+    prof_begin(c, ZK_PROF_SELECT, (pack ? 8 : 12) * n);
+    hipLaunchKernelGGL(reduce_by_key_kernel, dim3(st.tiles), dim3(RLE_BLOCK), 0, c->stream, sorted, w, (u64)n, uniq, sums, (u64)cap, lead, st,
+                       pack, d_max);
     prof_end(c);
     ZK_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(reduce_fixup_kernel, dim3((u32)div_up(st.tiles, 256)), dim3(256), 0, c->stream, lead, c->status, st.tiles, sums,
-                       (u64)cap, c->d_err);
+                       (u64)cap, c->d_err, d_max);
     ZK_HIP(c, hipGetLastError());
     ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, c->d_scalars + 9, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    if (d_max) ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 25, c->d_scalars + 25, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     *n_out = c->h_scalars[9];
+    if (max_sum) *max_sum = c->h_scalars[25] & 0xffffffffull;
     return check_device_error(c);
 }
 
@@ -496,20 +531,38 @@ int sample_heads(zk_ctx* c, const u64* keys, uint64_t n, uint64_t* sampled, uint
 
 // counts[(first output index of tile t) - 1] += lead[t]
 __global__ void rle_fixup_kernel(const u32* __restrict__ lead, const u64* __restrict__ status, u32 tiles, u32* counts,
-                                 u64 cap, u32* err) {
+                                 u64 cap, u32* err, u64* packed, int pack, u32* ovf) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0 || t >= tiles) return;
     const u32 l = lead[t];
     if (l == 0) return;
     const u64 excl = status[t - 1] & ZK_ST_VALUE_MASK;   // inclusive prefix of the tile before
     if (excl == 0 || excl - 1 >= cap) return;
-    const u32 old = atomicAdd(&counts[excl - 1], l);
-    if (old + l < old) atomicOr(err, ZK_DERR_COUNT_OVERFLOW);
+    if (counts) {
+        const u32 old = atomicAdd(&counts[excl - 1], l);
+        if (old + l < old) atomicOr(err, ZK_DERR_COUNT_OVERFLOW);
+    }
+    if (pack) {
+        // the count field of the packed word: add without ever carrying into the key (several tiles may add to one run)
+        const u64 top = (1ull << pack) - 1ull;
+        u64 w = packed[excl - 1];
+        while (true) {
+            const u64 cnt = (w & top) + l;
+            if (cnt > top) atomicOr(ovf, 1u);
+            const u64 nw = (w & ~top) | (cnt < top ? cnt : top);
+            const u64 seen = atomicCAS((unsigned long long*)&packed[excl - 1], (unsigned long long)w, (unsigned long long)nw);
+            if (seen == w) break;
+            w = seen;
+        }
+    }
 }
 
-int rle(zk_ctx* c, const u64* sorted, uint64_t n, u64* uniq, u32* counts, uint64_t cap, uint64_t* n_unique) {
+int rle(zk_ctx* c, const u64* sorted, uint64_t n, u64* uniq, u32* counts, uint64_t cap, uint64_t* n_unique, int pack, bool* overflow) {
     *n_unique = 0;
+    if (overflow) *overflow = false;
     if (n == 0) return ZK_OK;
+    u32* d_ovf = (u32*)(c->d_scalars + 24);
+    if (pack) ZK_HIP(c, hipMemsetAsync(d_ovf, 0, sizeof(u64), c->stream));
     SelState st;
     st.tiles = (u32)div_up(n, RLE_TILE);
     u32* lead;
@@ -517,15 +570,17 @@ int rle(zk_ctx* c, const u64* sorted, uint64_t n, u64* uniq, u32* counts, uint64
     ZK_TRY(lookback_begin(c, st.tiles, st.tiles, &st.epoch, &st.ticket_base));
     st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9;
     prof_begin(c, ZK_PROF_RLE, 8 * n);
-    hipLaunchKernelGGL(rle_kernel, dim3(st.tiles), dim3(RLE_BLOCK), 0, c->stream, sorted, (u64)n, uniq, counts, (u64)cap, lead, st);
+    hipLaunchKernelGGL(rle_kernel, dim3(st.tiles), dim3(RLE_BLOCK), 0, c->stream, sorted, (u64)n, uniq, counts, (u64)cap, lead, st, pack, d_ovf);
     prof_end(c);
     ZK_HIP(c, hipGetLastError());
     hipLaunchKernelGGL(rle_fixup_kernel, dim3((u32)div_up(st.tiles, 256)), dim3(256), 0, c->stream, lead, c->status, st.tiles,
-                       counts, (u64)cap, c->d_err);
+                       counts, (u64)cap, c->d_err, uniq, pack, d_ovf);
     ZK_HIP(c, hipGetLastError());
     ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, c->d_scalars + 9, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    if (pack) ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 24, c->d_scalars + 24, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     *n_unique = c->h_scalars[9];
+    if (pack && overflow) *overflow = (c->h_scalars[24] & 0xffffffffull) != 0;
     ZK_TRY(check_device_error(c));
     return ZK_OK;
 }
