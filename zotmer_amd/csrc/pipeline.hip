@@ -133,7 +133,7 @@ __global__ void max_u32_kernel(const u32* __restrict__ v, u64 n, u32* out) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) m = v[i] > m ? v[i] : m;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const u32 t = (u32)__shfl_xor((int)m, o, 64); m = t > m ? t : m; }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
 }
 
 static int max_u32(zk_ctx* c, const u32* v, uint64_t n, uint64_t* out) {

@@ -452,7 +452,8 @@ __global__ __launch_bounds__(RLE_BLOCK) void reduce_by_key_kernel(const u64* __r
     if (maxsum) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const u32 t = (u32)__shfl_xor((int)mx, o, 64); mx = t > mx ? t : mx; }
-        if (lane == 0 && mx) atomicMax(maxsum, mx);
+        // one word takes ~88 atomics per microsecond: only a wave that beats the value it can see asks for the atomic
+        if (lane == 0 && mx > __hip_atomic_load(maxsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxsum, mx);
     }
     if (threadIdx.x == 0) {
         lead[tile] = sm.lead;
@@ -471,7 +472,7 @@ __global__ void reduce_fixup_kernel(const u32* __restrict__ lead, const u64* __r
     if (excl == 0 || excl - 1 >= cap) return;
     const u32 old = atomicAdd(&sums[excl - 1], l);
     if (old + l < old) atomicOr(err, ZK_DERR_COUNT_OVERFLOW);
-    if (maxsum) atomicMax(maxsum, old + l);
+    if (maxsum && old + l > __hip_atomic_load(maxsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxsum, old + l);
 }
 
 // pack > 0: `sorted` holds (key << pack) | weight, `w` is ignored.  max_sum (may be null): the largest sum written.
