@@ -103,6 +103,7 @@ struct SortArgs {
     u32 glog;           // ... log2 of the run of consecutive tiles an XCD takes at a time
     u32 epoch;
     u32* err;
+    int prof_tag;       // 0: ZK_PROF_PASS_KEYS; else the tag this pass is timed under (zk_profile)
     u64* dbg;           // diagnostic build (-DZK_STAMPS) only: 8 time stamps per tile
     u64* dbg2;          // ... steps << 32 | spins of thread 0's look-back chain, per tile
 };
@@ -1150,7 +1151,8 @@ struct Sorter {
         a.err = c->d_err;
         a.dbg = c->dbg;
         a.dbg2 = c->dbg ? c->dbg + 8ull * tiles : nullptr;
-        prof_begin(c, SRC == SRC_STREAM ? ZK_PROF_PASS_STREAM : ZK_PROF_PASS_KEYS, SRC == SRC_STREAM ? a.n_bytes + 8 * a.n : 16 * a.n);
+        prof_begin(c, SRC == SRC_STREAM ? ZK_PROF_PASS_STREAM : (a.prof_tag ? a.prof_tag : ZK_PROF_PASS_KEYS),
+                   SRC == SRC_STREAM ? a.n_bytes + 8 * a.n : 16 * a.n);
         hipLaunchKernelGGL((pass_pipe_kernel<C, SRC>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
         prof_end(c);
         ZK_HIP(c, hipGetLastError());
@@ -1201,6 +1203,7 @@ struct Sorter {
         ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * C::RADIX, (void**)&ghist));
         SortArgs a = {};
         a.kin = keys; a.n = n;
+        a.prof_tag = lo_bit ? ZK_PROF_PASS_PACKED : 0;      // the upper-bit passes over collapsed / packed lists are timed apart
         ZK_TRY(launch_hist<SRC_ARRAY>(c, a, plan, ghist, nullptr, c->d_scalars + 8));
         u64* in = keys; u64* out = alt;
         for (int p = 0; p < plan.passes; p++) {
