@@ -291,7 +291,7 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
             in_aux = true;
         } else {
             u64* res = nullptr;
-            ZK_TRY(sort_keys_upper(c, sorted, other, n, 2 * K, collapse_bit, &res));
+            ZK_TRY(sort_keys_upper(c, sorted, other, n, 2 * K, collapse_bit, &res, ZK_PROF_PASS_KEYS));      // still every key: the dominant passes
             sorted = res;
             other = (sorted == buf_a) ? buf_b : buf_a;
             cnt = (u32*)other;

@@ -1197,13 +1197,13 @@ struct Sorter {
     }
 
     // lo_bit > 0: only the bits [lo_bit, key_bits) are sorted (the input is already ordered by the bits below)
-    static int sort_keys(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** result, int lo_bit = 0) {
+    static int sort_keys(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** result, int lo_bit = 0, int prof_tag = 0) {
         PassPlan plan = make_plan(key_bits - lo_bit, C::RBITS, lo_bit);
         u64* ghist;
         ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * C::RADIX, (void**)&ghist));
         SortArgs a = {};
         a.kin = keys; a.n = n;
-        a.prof_tag = lo_bit ? ZK_PROF_PASS_PACKED : 0;      // the upper-bit passes over collapsed / packed lists are timed apart
+        a.prof_tag = prof_tag;      // the upper-bit passes over collapsed / packed lists are timed apart
         ZK_TRY(launch_hist<SRC_ARRAY>(c, a, plan, ghist, nullptr, c->d_scalars + 8));
         u64* in = keys; u64* out = alt;
         for (int p = 0; p < plan.passes; p++) {
@@ -1338,10 +1338,10 @@ int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n,
 }
 
 // keys already ordered by their low `lo_bit` bits: LSD passes over the bits above only
-int sort_keys_upper(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, int lo_bit, u64** result) {
+int sort_keys_upper(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, int lo_bit, u64** result, int prof_tag) {
     *result = keys;
     if (n == 0 || lo_bit >= key_bits) return ZK_OK;
-    ZK_SORT_DISPATCH(c, sort_keys(c, keys, alt, n, key_bits, result, lo_bit));
+    ZK_SORT_DISPATCH(c, sort_keys(c, keys, alt, n, key_bits, result, lo_bit, prof_tag));
 }
 
 // pairs already ordered by their low `lo_bit` bits: LSD passes over the bits above only
