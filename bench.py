@@ -546,7 +546,7 @@ def main():
         pk = prof.get("pass_keys", dict(launches=0, ms=0.0, bytes=0))
         ach = (pk["bytes"] / 1e9) / (pk["ms"] / 1e3) if pk["ms"] else 0.0
         mb = model_bytes(n_bytes, st.n_instances, st.n_unique, K)
-        traffic = measured_traffic("pass_pipe_kernel<zk::Cfg<512, 16, 9, 1, 4, 32, true>, 0>", st.n_windows)
+        traffic = measured_traffic("pass_pipe_kernel<zk::Cfg<512, 16, 9, 1, 4, 32, true>, 0, 0>", st.n_windows)
         out = {
             "metric": "Gk-mers/sec kmerize k=25 on synthetic 150bp FASTQ; achieved HBM GB/s fraction",
             "value": value, "unit": "Gk-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

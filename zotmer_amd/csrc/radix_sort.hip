@@ -780,7 +780,9 @@ struct PipeSmem {
     u32 total_live;
 };
 
-template <class C, int SRC>
+// VAR only names the instantiation: 1 = the upper-bit passes over collapsed lists of packed words, so that a profiler lists them
+// apart from the dominant full-size passes (same code).
+template <class C, int SRC, int VAR = 0>
 __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a, u32 tiles) {
     constexpr int BLOCK = C::BLOCK, ITEMS = C::ITEMS, RADIX = C::RADIX, NW = C::NW, DPT = C::DPT, TILE = C::TILE;
     static_assert(C::ROUNDS == 1, "the pipeline parks a whole tile in LDS");
@@ -1153,7 +1155,10 @@ struct Sorter {
         a.dbg2 = c->dbg ? c->dbg + 8ull * tiles : nullptr;
         prof_begin(c, SRC == SRC_STREAM ? ZK_PROF_PASS_STREAM : (a.prof_tag ? a.prof_tag : ZK_PROF_PASS_KEYS),
                    SRC == SRC_STREAM ? a.n_bytes + 8 * a.n : 16 * a.n);
-        hipLaunchKernelGGL((pass_pipe_kernel<C, SRC>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
+        if (SRC == SRC_ARRAY && a.prof_tag == ZK_PROF_PASS_PACKED)
+            hipLaunchKernelGGL((pass_pipe_kernel<C, SRC, 1>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
+        else
+            hipLaunchKernelGGL((pass_pipe_kernel<C, SRC, 0>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
         prof_end(c);
         ZK_HIP(c, hipGetLastError());
       }
