@@ -451,12 +451,9 @@ def main():
         ct = torch.empty(cap, dtype=torch.int32, device="cuda")
         out_k = native.DeviceArray.borrow(ctx, kt.data_ptr(), np.uint64, cap, keep=kt)
         out_c = native.DeviceArray.borrow(ctx, ct.data_ptr(), np.uint32, cap, keep=ct)
-        try:
-            comm = parallel.make_comm(ctx, dist)
-        except Exception as e:      # recorded in the JSON line, never silent
-            comm_note = "zk_comm init failed (%s); torch.distributed transport used" % e
-            sys.stderr.write(comm_note + "\n")
-            comm = parallel.TorchComm(dist)
+        notes = []
+        comm = parallel.make_comm(ctx, dist, notes)     # probes the native transport on every rank; a switch is recorded in the line
+        comm_note = notes[0] if notes else None
         par = parallel.Exchange(ctx, dist, K, owner=os.environ.get("ZOT_OWNER", "range"), comm=comm)
     else:
         out_k, out_c = ctx.empty(cap, np.uint64), ctx.empty(cap, np.uint32)

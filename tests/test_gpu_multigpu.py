@@ -150,3 +150,42 @@ def test_rccl_transports_with_one_rank():
             json.dump(rec, f, indent=1)
     assert r.returncode == 0, (rec, r.stderr[-3000:])
     assert rec["torch_chunked_verified"] and rec["native_verified"] and rec["native_allreduce"] and rec["chunked_gt_1GiB_intact"]
+
+
+def test_commands_distributed_code_path_with_one_rank(tmp_path):
+    """`zot kmerize | merge | dist` through their multi-GPU code (engine.distributed -> parallel.Exchange -> zk_comm_*) with ONE
+    rank (ZOT_FORCE_DIST=1): the files and the stdout must equal what the plain single-GPU commands give."""
+    from zotmer_amd import synth as sy
+    fq = []
+    for i in range(2):
+        p = tmp_path / ("r%d.fastq" % i)
+        p.write_text(sy.fastq_text(sy.DEFAULT_SEED, 3000 * i, 4000, 150, genome=50000, sub_thr=sy.frac32(0.005), n_thr=sy.frac32(0.0005)))
+        fq.append(str(p))
+    zot = os.path.join(ROOT, "zot")
+
+    def run(env_extra, *args):
+        env = dict(os.environ, **env_extra)
+        r = subprocess.run([sys.executable, zot] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stderr[-3000:]
+        return r.stdout
+
+    def members(path):
+        from zotmer_amd.library.container import Container
+        with Container(str(path), "r") as z:
+            return {nm: z.read(nm) for nm, _ in z.names() if nm != "__meta__"}, json.loads(z.read("__meta__").decode())
+
+    outs = {}
+    for tag, env in (("plain", {}), ("dist", {"ZOT_FORCE_DIST": "1"}), ("dist_hash_torch", {"ZOT_FORCE_DIST": "1", "ZOT_OWNER": "hash", "ZOT_COMM": "torch"})):
+        a, b, m = tmp_path / (tag + "_a.k25"), tmp_path / (tag + "_b.k25"), tmp_path / (tag + "_m.k25")
+        run(env, "kmerize", 25, a, fq[0])
+        run(env, "kmerize", 25, b, fq[1])
+        run(env, "merge", m, a, b, a)
+        d25 = run(env, "dist", "-M", "*.qual", 25, a, b).replace(tag + "_", "")
+        d12 = run(env, "dist", "-M", "jaccard.qual", 12, a, b).replace(tag + "_", "")
+        outs[tag] = (members(a), members(b), members(m), d25, d12)
+    for tag in ("dist", "dist_hash_torch"):
+        for i in range(3):
+            assert outs[tag][i][0] == outs["plain"][i][0], (tag, i)            # codec64 streams byte for byte
+            for key in ("K", "hist", "acgt", "reads"):
+                assert outs[tag][i][1].get(key) == outs["plain"][i][1].get(key), (tag, i, key)
+        assert outs[tag][3] == outs["plain"][3] and outs[tag][4] == outs["plain"][4]

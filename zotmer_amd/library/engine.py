@@ -32,6 +32,16 @@ def distributed():
     """(dist, world, rank) when launched by torch.distributed.run with WORLD_SIZE > 1, else (None, 1, 0).  torch is
     imported (before libzotk is loaded, so that both bind the same HIP runtime) only in that case."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 and os.environ.get("ZOT_FORCE_DIST") == "1":
+        # rehearse the multi-GPU code path of a command with ONE rank (what a one-GPU box can check on hardware)
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29541")):
+            os.environ.setdefault(k, v)
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            torch.cuda.set_device(0)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        return dist, 1, 0
     if world <= 1:
         return None, 1, 0
     from zotmer_amd import parallel

@@ -543,9 +543,41 @@ def init_from_env(ctx=None, owner=None):
     return dist
 
 
-def make_comm(ctx, dist):
-    """The transport ZOT_COMM asks for: 'native' (zk_comm_*, the default on the GPU) or 'torch'."""
+def make_comm(ctx, dist, notes=None):
+    """The transport ZOT_COMM asks for: 'native' (zk_comm_*, the default on the GPU) or 'torch'.  The native transport is
+    probed once -- a small all-to-all-v and an all-reduce checked on every rank -- and every rank learns through
+    torch.distributed whether ALL of them passed; if not, all of them use torch.distributed instead, and say so (`notes`, a
+    list, receives the reason: callers print it / put it in their report -- the switch is never silent)."""
     want = os.environ.get("ZOT_COMM", "native")
-    if want == "native" and dist.get_backend() == "nccl":
-        return NativeComm(ctx, dist)
+    if not (want == "native" and dist.get_backend() == "nccl"):
+        return TorchComm(dist)
+    comm, why = None, ""
+    try:
+        comm = NativeComm(ctx, dist)
+        W, r = comm.world, comm.rank
+        src = torch.arange(W * 4, dtype=torch.int64, device="cuda") + 1000 * r
+        dst = torch.zeros(W * 4, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        comm.all_to_all_v(dst, src, [4] * W, [4] * W, [4 * i for i in range(W + 1)], [4 * i for i in range(W + 1)])
+        want_t = torch.cat([torch.arange(4 * r, 4 * r + 4, dtype=torch.int64, device="cuda") + 1000 * q for q in range(W)])
+        ok = bool(torch.equal(dst, want_t)) and comm.all_reduce([r + 1, 1 << 40]) == [W * (W + 1) // 2, (W << 40) & M64]
+        if not ok:
+            why = "probe exchange returned wrong data"
+    except Exception as e:       # noqa: BLE001 -- any failure of the optional transport selects the other one, on every rank
+        ok, why = False, "%s: %s" % (type(e).__name__, e)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device="cuda")
+    if dist.get_world_size() > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return comm
+    if comm is not None:
+        try:
+            comm.close()
+        except Exception:        # noqa: BLE001
+            pass
+    msg = "zk_comm transport not usable on every rank (%s); torch.distributed transport used" % (why or "another rank failed")
+    if notes is not None:
+        notes.append(msg)
+    import sys
+    sys.stderr.write(msg + "\n")
     return TorchComm(dist)
