@@ -136,7 +136,7 @@ def _run(script, *args, timeout=900):
 
 def test_merge_and_dist_over_8_logical_ranks_on_one_gpu():
     r = _run("_logical_ranks_gpu.py")
-    assert r.returncode == 0 and r.stdout.count("LOGICAL-RANKS-OK") == 2, r.stdout[-2000:] + r.stderr[-6000:]
+    assert r.returncode == 0 and r.stdout.count("LOGICAL-RANKS-OK") == 2, r.stdout[-6000:] + r.stderr[-2000:]
 
 
 def test_rccl_transports_with_one_rank():
