@@ -39,8 +39,11 @@ def distributed():
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
+            from zotmer_amd import parallel
             torch.cuda.set_device(0)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+            with parallel.stdout_to_stderr():
+                dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+                dist.barrier()
         return dist, 1, 0
     if world <= 1:
         return None, 1, 0

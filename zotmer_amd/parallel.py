@@ -41,6 +41,25 @@ import torch
 M64 = 0xFFFFFFFFFFFFFFFF
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when a process creates its first communicator; the commands' stdout is their
+    result (`zot dist` prints a table).  File descriptor 1 points at stderr while communicators are made."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *a):
+        import sys
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def splitters(K, world):
     """world-1 ascending EQUAL-WIDTH cut points of [0, 4**K) (static; the commands use balanced_cuts)."""
     space = 1 << (2 * K)
@@ -539,7 +558,9 @@ def init_from_env(ctx=None, owner=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not dist.is_initialized():
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.barrier()          # makes torch's communicator (and RCCL's banner) now
     return dist
 
 
@@ -553,7 +574,8 @@ def make_comm(ctx, dist, notes=None):
         return TorchComm(dist)
     comm, why = None, ""
     try:
-        comm = NativeComm(ctx, dist)
+        with stdout_to_stderr():
+            comm = NativeComm(ctx, dist)
         W, r = comm.world, comm.rank
         src = torch.arange(W * 4, dtype=torch.int64, device="cuda") + 1000 * r
         dst = torch.zeros(W * 4, dtype=torch.int64, device="cuda")
