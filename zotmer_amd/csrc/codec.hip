@@ -252,7 +252,7 @@ __device__ __forceinline__ u32 lookback_state(u64* status, u32 tile, u32 my_map,
         u64 w = ld_agent(&status[t - 1]);
         int spins = 0;
         while (st_state(w, epoch) == 0) {
-            if (++spins > ZK_SPIN_LIMIT) { atomicOr(err, ZK_DERR_SPIN_TIMEOUT); break; }
+            if (++spins > ZK_SPIN_LIMIT) { atomicOr(err, ZK_DERR_SPIN_TIMEOUT | (256u << 8)); break; }
             __builtin_amdgcn_s_sleep(1);
             w = ld_agent(&status[t - 1]);
         }

@@ -123,7 +123,7 @@ __device__ __forceinline__ u64 lookback_exclusive(u64* status, u32 tile, u64 tot
         u64 need = incl ? ((incl & (0ull - incl)) - 1) | (incl & (0ull - incl)) : ~0ull;  // lanes <= first inclusive
         if (empty & need) {
             if (++spins > ZK_SPIN_LIMIT) {
-                if (l == 0) atomicOr(err, ZK_DERR_SPIN_TIMEOUT);
+                if (l == 0) atomicOr(err, ZK_DERR_SPIN_TIMEOUT | (512u << 8));
                 break;
             }
             __builtin_amdgcn_s_sleep(1);

@@ -130,7 +130,10 @@ int check_device_error(zk_ctx* c) {
         (void)hipMemsetAsync(c->d_ticket, 0, sizeof(u32), c->stream);
         c->ticket_base = 0;
         c->epoch = 0;
-        return fail(c, ZK_EINTERNAL, "device look-back spin limit reached (kernel bug or lost workgroup)");
+        // bits 8.. say which wait gave up: 0x01-0x20 radix_sort.hip in file order (array-pass walk, the two segmented-sort waits,
+        // scanner waiting for counts, scanner wave hand-off, tile waiting for offsets), 0x100 codec.hip parse state,
+        // 0x200 common.hpp look-back
+        return fail(c, ZK_EINTERNAL, "device look-back spin limit reached (kernel bug or lost workgroup; wait sites 0x%x)", e >> 8);
     }
     if (e & ZK_DERR_RANGE) return fail(c, ZK_ERANGE, "a value (or k-mer delta) >= 2^60 cannot be stored in the codec64 format");
     if (e & ZK_DERR_BAD_TAG) return fail(c, ZK_ERANGE, "corrupt codec64 stream (unknown tag)");
@@ -204,12 +207,16 @@ zk_ctx* zk_create(int device, uint64_t workspace_bytes) {
     ZK_CREATE_STEP(hipMalloc((void**)&c->d_err, sizeof(u32)));
     ZK_CREATE_STEP(hipMalloc((void**)&c->d_scalars, 64 * sizeof(u64)));
     ZK_CREATE_STEP(hipHostMalloc((void**)&c->h_scalars, 64 * sizeof(u64), hipHostMallocDefault));
-    ZK_CREATE_STEP(hipMemset(c->d_ticket, 0, sizeof(u32)));
+    // On the context's OWN stream, then waited for: hipMemset runs on the null stream, asynchronously for device memory, and a
+    // non-blocking stream does not order against it -- with other threads keeping the null stream busy the clear of the
+    // ticket counter could land in the middle of this context's first kernel (duplicate tickets, no scanner, spin timeout).
+    ZK_CREATE_STEP(hipMemsetAsync(c->d_ticket, 0, sizeof(u32), c->stream));
     ZK_CREATE_STEP(hipMalloc((void**)&c->d_xticket, 8 * 32 * sizeof(u32)));
-    ZK_CREATE_STEP(hipMemset(c->d_xticket, 0, 8 * 32 * sizeof(u32)));
+    ZK_CREATE_STEP(hipMemsetAsync(c->d_xticket, 0, 8 * 32 * sizeof(u32), c->stream));
+    ZK_CREATE_STEP(hipMemsetAsync(c->d_err, 0, sizeof(u32), c->stream));
+    ZK_CREATE_STEP(hipMemsetAsync(c->d_scalars, 0, 64 * sizeof(u64), c->stream));
+    ZK_CREATE_STEP(hipStreamSynchronize(c->stream));
     c->num_xcd = probe_xcds(c);
-    ZK_CREATE_STEP(hipMemset(c->d_err, 0, sizeof(u32)));
-    ZK_CREATE_STEP(hipMemset(c->d_scalars, 0, 64 * sizeof(u64)));
     if (workspace_bytes) {
         ZK_CREATE_STEP(hipMalloc((void**)&c->arena, workspace_bytes));
         c->arena_size = workspace_bytes;

@@ -453,7 +453,7 @@ __device__ __forceinline__ u64 lookback_walk(const u64* q, u32 tile, int radix, 
         u64 w = ld_agent(q);
         int spins = 0;
         while (st_state(w, epoch) == 0) {
-            if (++spins > ZK_SPIN_LIMIT) { atomicOr(err, ZK_DERR_SPIN_TIMEOUT); break; }
+            if (++spins > ZK_SPIN_LIMIT) { atomicOr(err, ZK_DERR_SPIN_TIMEOUT | (1u << 8)); break; }
             __builtin_amdgcn_s_sleep(1);
             w = ld_agent(q);
         }
@@ -514,7 +514,7 @@ __device__ __forceinline__ u64 lookback_segmented(const SortArgs& a, u32 tile, i
             u16 x = w[k];
             int spins = 0;
             while (!(x & 0x8000u)) {
-                if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT); break; }
+                if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT | (2u << 8)); break; }
                 __builtin_amdgcn_s_sleep(1);
                 x = ld_agent16(row - (long long)(i0 + k) * RADIX);
             }
@@ -532,7 +532,7 @@ __device__ __forceinline__ u64 lookback_segmented(const SortArgs& a, u32 tile, i
         u64 w = (g == seg) ? bw : ld_agent(q);
         int spins = 0;
         while (st_state(w, a.epoch) == 0) {
-            if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT); break; }
+            if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT | (4u << 8)); break; }
             __builtin_amdgcn_s_sleep(1);
             w = ld_agent(q);
         }
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
 #pragma unroll
                 for (int k = 0; k < U; k++) all &= x[k];
                 if (all & 0x8000u) break;
-                if (spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT); break; }
+                if (spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT | (8u << 8)); break; }
                 __builtin_amdgcn_s_sleep(2);
 #pragma unroll
                 for (int k = 0; k < U; k++)
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
             u64 cv = *cw;
             int spins = 0;
             while ((u32)(cv >> 40) != b) {
-                if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT); break; }
+                if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT | (16u << 8)); break; }
                 __builtin_amdgcn_s_sleep(1);
                 cv = *cw;
             }
@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                     u64 w = vB ? rowA[j] : ld_agent(q);
                     int spins = 0;
                     while (st_state(w, a.epoch) == 0) {
-                        if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT); break; }
+                        if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT | (32u << 8)); break; }
                         __builtin_amdgcn_s_sleep(1);
                         w = ld_agent(q);
                     }
