@@ -294,12 +294,14 @@ def test_kmerize_short_sort_paths_agree(ctx, K):
         ctx.tune(short_sort=0, side_div=8)
 
 
-@pytest.mark.parametrize("K", [9, 14, 25, 31, 32])
+@pytest.mark.parametrize("K", [9, 14, 25, 26, 27, 31, 32])
 def test_kmerize_early_collapse_paths_agree(ctx, K):
     """zk_kmerize (canonical) counts runs after the passes over the low bits and finishes the sort on (k-mer, count) pairs when a
     sample says the reads repeat their k-mers; otherwise the keys finish the sort.  Both ways, and with the collapse switched
     off, the arrays must be the oracle's -- also when distinct k-mers share all their low bits, so that their copies interleave
-    and the final reduce has to add up split runs."""
+    and the final reduce has to add up split runs.  early_collapse = 1 counts the runs inside the tile-local ranking of the last
+    low digit (collapse_kernel: K <= 27, where a pair packs into one word; K = 26, 27 have fewer than 14 spare bits, so long runs
+    are cut every 512 slots), 2 as a pass of its own."""
     rng = np.random.default_rng(100 + K)
     deep = synth.read_strings(11, 0, 6000, 150, genome=12000, sub_thr=synth.frac32(0.004), n_thr=synth.frac32(0.001))   # ~60x: collapses
     flat = synth.read_strings(12, 0, 3000, 150, genome=0)                                                              # no repeats: refused
@@ -314,7 +316,7 @@ def test_kmerize_early_collapse_paths_agree(ctx, K):
         want = zo.kmerize(K, reads)
         d = ctx.upload_stream(stream_of(reads))
         try:
-            for on, packed in ((1, 1), (1, 0), (0, 1), (0, 0)):
+            for on, packed in ((1, 1), (2, 1), (1, 0), (0, 1), (0, 0)):
                 ctx.tune(early_collapse=on, packed_pairs=packed)
                 k, c, st = ctx.kmerize(d, K)
                 assert np.array_equal(k.to_host(), want["kmers"]), (name, on, packed)

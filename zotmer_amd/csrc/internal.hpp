@@ -19,7 +19,9 @@ struct zk_ctx {
                                // pays off on uncorrelated reads only)
     int packed_pairs = 1;      // (k-mer, count) pairs travel as ONE word (k-mer << s | count) through the key kernel when the counts fit the
                                // spare bits above 2K (pipeline.hip); zk_tune, tests
-    int early_collapse = 1;    // zk_kmerize (canonical): run-length count after the low-bit passes, finish the sort on pairs (pipeline.hip)
+    int early_collapse = 1;    // zk_kmerize (canonical): run-length count after the low-bit passes, finish the sort on pairs (pipeline.hip);
+                               // 1 = counted inside the tile-local ranking of the last of those digits (collapse_kernel) when the pairs pack,
+                               // 2 = always as a pass of its own
     int side_div = 8;          // ... side list capacity = n / side_div (tests shrink it to force the fallback)
     int pairs_variant = 2;     // ... for (key, u32) pairs
 
@@ -116,6 +118,9 @@ int sort_pairs_mirrored(zk_ctx* c, const u64* src_k, const u32* src_v, u64* keys
 // sort whose first pass generates the keys from a base stream (encode.hip + radix_sort.hip)
 struct StreamSrc { const u8* stream; uint64_t n_bytes; int K; int mode; int lo_bit; int hi_bit = 0; };   // mode: ZK_KEYS_*; sort bits [lo_bit, hi_bit) (hi_bit 0 = 2K)
 int sort_rbits(zk_ctx* c);
+int sort_first_bits(zk_ctx* c, int key_bits, int lo_bit);
+int collapse_pass(zk_ctx* c, const u64* keys, uint64_t n, int shift, int bits, int pack, u64* out, uint64_t cap, uint64_t* n_out,
+                  uint64_t max_tiles = 0);
 int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,
                 uint64_t acgt[4], u64** result);
 // select.hip

@@ -223,12 +223,14 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     StreamSrc src{stream, n_bytes, K, both ? ZK_KEYS_BOTH : ZK_KEYS_CANONICAL, 0};
     // low bits to sort before looking for runs: 2^b >= 8 x keys, a whole number of passes, and at least one pass left over
     int collapse_bit = 0;
+    int fused_bit = 0;            // > 0: the low passes stop here; the next digit is ranked tile by tile and counted by collapse_kernel
+    const int rb = sort_rbits(c);
     if (!both && c->early_collapse) {
-        const int rb = sort_rbits(c);
         const int b = rb * ((ilog2_ceil(n_bytes) + 3 + rb - 1) / rb);
         if (b + rb / 2 < 2 * K) collapse_bit = b;
+        if (collapse_bit >= 2 * rb && c->early_collapse == 1 && c->packed_pairs && pack_bits_for(K)) fused_bit = collapse_bit - rb;
     }
-    src.hi_bit = collapse_bit;
+    src.hi_bit = fused_bit ? fused_bit : collapse_bit;
     uint64_t n = 0;
     u64* sorted = nullptr;
     ZK_TRY(sort_stream(c, src, buf_a, buf_b, cap_keys, &n, st->acgt, &sorted));
@@ -245,6 +247,37 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     bool in_aux = false;          // the counted list lives in the aux region (collapse path): both sort buffers are free
     uint64_t max_count = 0;       // largest count of the list, when it came for free (packed reduce)
     bool have_max = false;
+    if (fused_bit && n) {
+        // Runs are counted inside the tile-local ranking of the next digit above fused_bit (radix_sort.hip::collapse_kernel):
+        // that pass writes one word per run instead of every key, and no pass of its own reads the keys again to count.  Its
+        // output is tile-major, so the passes over the words start at fused_bit.  Whether it pays: the same kernel over the
+        // first tiles (low bits ascending: a random subset of the k-mers with all their copies).
+        const int pk = pack_bits_for(K);
+        const int cb = sort_first_bits(c, 2 * K + pk, fused_bit + pk);       // the digit the first pass over the words will use
+        const uint64_t sample_tiles = 64, tile_keys = 8192;
+        uint64_t us = 0, u1 = 0;
+        ZK_TRY(collapse_pass(c, sorted, n, fused_bit, cb, pk, other, cap_keys, &us, sample_tiles));
+        const uint64_t m = n < sample_tiles * tile_keys ? n : sample_tiles * tile_keys;
+        if ((double)us <= 0.6 * (double)m) {
+            ZK_TRY(collapse_pass(c, sorted, n, fused_bit, cb, pk, other, cap_keys, &u1));
+            u64* res = nullptr;
+            ZK_TRY(sort_keys_upper(c, other, sorted, u1, 2 * K + pk, fused_bit + pk, &res));
+            const uint64_t a8 = (8 * u1 + 255) & ~255ull, a4 = (4 * u1 + 255) & ~255ull;
+            char* aux;
+            ZK_TRY(aux_require(c, a8 + a4, &aux));
+            ZK_TRY(reduce_by_key(c, res, nullptr, u1, (u64*)aux, (u32*)(aux + a8), u1, &uc, pk, &max_count));
+            sorted = (u64*)aux; cnt = (u32*)(aux + a8);
+            in_aux = true;
+            have_max = true;
+        } else {
+            u64* res = nullptr;
+            ZK_TRY(sort_keys_upper(c, sorted, other, n, 2 * K, fused_bit, &res, ZK_PROF_PASS_KEYS));      // little duplication: every key to the end
+            sorted = res;
+            other = (sorted == buf_a) ? buf_b : buf_a;
+            cnt = (u32*)other;
+        }
+        collapse_bit = 0;
+    }
     if (collapse_bit && n) {
         uint64_t m = 0, heads = 0;
         ZK_TRY(sample_heads(c, sorted, n, &m, &heads));

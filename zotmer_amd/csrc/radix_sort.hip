@@ -723,6 +723,198 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_kernel(SortArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Collapse pass (zk_kmerize, canonical keys; see pipeline.hip::kmerize_full).
+//
+// Input: the keys ordered by their low `shift` bits, where 2^shift is within a factor of a tile of the number of keys -- so
+// all copies of a k-mer (they share every bit) sit within a few dozen slots of each other, i.e. nearly always in ONE tile,
+// interleaved with the few other k-mers that share their low bits.  The tile is ranked by the NEXT digit exactly as a sort
+// pass would and parked in LDS grouped by that digit: inside a digit group the keys are still in input order, hence ordered
+// by shift + bits low bits, hence equal keys are neighbours.  Instead of scattering the 8192 keys to the digit's global
+// place, the runs are counted right there and the tile writes one word (key << pack | run length) per run, tiles one after
+// the other (a one-word look-back per tile; no global histogram of this digit is needed at all).
+//
+// The output is NOT ordered by the digit across tiles -- it is tile-major -- so the upper-bit passes that follow start at
+// bit `shift`, not shift + bits: inside (tile, digit group) the words ascend by their low `shift` bits and the tiles
+// partition the range of those bits in ascending order, so for any digit value the stable pass collects tile 0's group,
+// tile 1's group, ... = ascending low bits.  This needs the FIRST of those passes to use exactly this digit (a narrower one
+// would concatenate two groups of one tile, whose low bits overlap): the caller takes `bits` from sort_first_bits.
+// LSD invariant kept; a run cut by a tile edge (or a k-mer whose copies were not neighbours) yields two words with the
+// same key, which reduce_by_key adds up after the sort, as before.
+// `split`: runs are also cut every 512 slots so that a length always fits `pack` < 14 bits.
+//
+// Measured alternatives (config 2, 6.2 G keys; this version 21 ms): a persistent variant that prefetches the next tile's keys
+// -- with the one-word look-back all resident workgroups fall into lock step (2.5x slower); with per-workgroup output
+// regions and a compacting copy instead of the look-back no faster (the kernel is bound by its ~1800 vector instructions
+// per thread, not by the loads); counting in an LDS hash table (compare-and-swap claims, adds count; output in input
+// order, no ranking at all) 30-35 ms: the copies of a k-mer sit in the same 64 lanes, so every atomic instruction carries
+// several same-address conflicts (SQ_LDS_BANK_CONFLICT 43 % of the kernel's cycles).
+// ---------------------------------------------------------------------------------------
+template <int RBITS>
+struct CollapseSmem {
+    static constexpr int BLOCK = 512, ITEMS = 16, TILE = BLOCK * ITEMS, RADIX = 1 << RBITS, NW = BLOCK / 64, CHUNKS = TILE / 64;
+    u64 exch[TILE];
+    u16 cnt[NW][RADIX];
+    u32 digit_off[RADIX];
+    u64 mask[CHUNKS];           // head flags of slots [64 q, 64 q + 64)
+    u32 hbase[CHUNKS];          // heads before chunk q
+    u32 nexth[CHUNKS];          // first head at or after slot 64 (q + 1)
+    u32 wsum[NW];
+    u32 ticket;
+    u32 total_live;
+    u32 heads;
+    u64 gbase;
+};
+
+struct CollapseArgs {
+    const u64* kin;
+    u64 n;
+    u64* out;
+    u64 cap;
+    int shift, bits, pack, split;
+    u64* status;
+    u32* ticket;
+    u32 ticket_base;
+    u32 epoch;
+    u32* err;
+    u64* d_total;
+    u32 tiles;
+};
+
+template <int RBITS>
+__global__ __launch_bounds__(512, 4) void collapse_kernel(CollapseArgs a) {
+    using S = CollapseSmem<RBITS>;
+    constexpr int BLOCK = S::BLOCK, ITEMS = S::ITEMS, TILE = S::TILE, RADIX = S::RADIX, NW = S::NW, CHUNKS = S::CHUNKS;
+    static_assert(RADIX <= BLOCK, "one digit per thread");
+    __shared__ S sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 tile = take_ticket(a.ticket, &sm.ticket) - a.ticket_base;
+    // as load_tile: a wave takes 64 * ITEMS consecutive keys (the ranks below number them wave by wave, row by row)
+    const u64 base = (u64)tile * TILE + (u64)wave * (64 * ITEMS) + lane;
+    const u32 dmask = (1u << a.bits) - 1u;
+
+    u64 key[ITEMS];
+    u32 live = 0;
+    if ((u64)(tile + 1) * TILE <= a.n) {
+        const u64* p = a.kin + base;
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) key[i] = p[i * 64];
+        live = (1u << ITEMS) - 1u;
+    } else {
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const u64 g = base + (u64)i * 64;
+            key[i] = 0;
+            if (g < a.n) { key[i] = a.kin[g]; live |= 1u << i; }
+        }
+    }
+    u16* mycnt = sm.cnt[wave];
+    for (int q = lane; q < RADIX / 8; q += 64) reinterpret_cast<uint4*>(mycnt)[q] = make_uint4(0, 0, 0, 0);
+
+    // ---- rank inside the wave (see pass_kernel) -------------------------------------------------
+    u32 rank2[ITEMS / 2];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const bool lv = (live >> i) & 1u;
+        const u32 d = (u32)(key[i] >> a.shift) & dmask;
+        u32 plo, phi;
+        match_digit<RBITS>(d, __ballot(lv), plo, phi);
+        const u32 below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+        const u32 npeer = (u32)__popc(plo) + (u32)__popc(phi);
+        const u32 pre = lv ? (u32)mycnt[d] : 0u;
+        if (i & 1) rank2[i / 2] |= (pre + below) << 16; else rank2[i / 2] = pre + below;
+        if (lv && below == npeer - 1) mycnt[d] = (u16)(pre + npeer);
+    }
+    __syncthreads();
+    // ---- per digit: exclusive scan over the waves, then over the digits ----------------------------
+    u32 acc = 0;
+    if (tid < RADIX) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const u32 t = sm.cnt[w][tid];
+            sm.cnt[w][tid] = (u16)acc;
+            acc += t;
+        }
+    }
+    const u32 inc = wave_incl_scan_u32(acc);
+    if (lane == 63) sm.wsum[wave] = inc;
+    __syncthreads();
+    {
+        u32 woff = 0;
+        for (int w = 0; w < wave; w++) woff += sm.wsum[w];
+        if (tid < RADIX) sm.digit_off[tid] = woff + inc - acc;
+        if (tid == BLOCK - 1) sm.total_live = woff + inc;
+    }
+    __syncthreads();
+    // ---- park, grouped by digit ------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const u32 d = (u32)(key[i] >> a.shift) & dmask;
+        if ((live >> i) & 1u) sm.exch[sm.digit_off[d] + sm.cnt[wave][d] + ((rank2[i / 2] >> (16 * (i & 1))) & 0xffffu)] = key[i];
+    }
+    __syncthreads();
+    const u32 total = sm.total_live;
+    // ---- heads of the runs: slot s = 512 i + tid, chunk q = 8 i + wave --------------------------------
+    u32 headbits = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const u32 s = (u32)i * BLOCK + tid;
+        const u64 k = sm.exch[s];
+        const u64 prev = sm.exch[s ? s - 1 : 0];
+        key[i] = k;
+        const bool head = s < total && (s == 0 || k != prev || (a.split && tid == 0));
+        const u64 m = __ballot(head);
+        if (lane == 0) sm.mask[i * NW + wave] = m;
+        headbits |= (head ? 1u : 0u) << i;
+    }
+    __syncthreads();
+    // ---- heads before every chunk, first head after it; the tile's place in the output -----------------------
+    if (wave == 0) {
+        static_assert(CHUNKS == 128, "two chunks per lane");
+        const u64 m0 = sm.mask[2 * lane], m1 = sm.mask[2 * lane + 1];
+        const u32 p0 = (u32)__popcll(m0), p1 = (u32)__popcll(m1);
+        const u32 in2 = wave_incl_scan_u32(p0 + p1);
+        sm.hbase[2 * lane] = in2 - p0 - p1;
+        sm.hbase[2 * lane + 1] = in2 - p1;
+        // first head in the chunks AFTER q (suffix minimum over the chunks' first heads; `total` if there is none)
+        const u32 f0 = m0 ? (u32)(2 * lane) * 64 + (u32)__builtin_ctzll(m0) : 0xffffffffu;
+        const u32 f1 = m1 ? (u32)(2 * lane + 1) * 64 + (u32)__builtin_ctzll(m1) : 0xffffffffu;
+        u32 suf = f0 < f1 ? f0 : f1;          // inclusive suffix minimum over the lanes' pairs
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 t = (u32)__shfl_down((int)suf, o, 64);
+            if (lane + o < 64 && t < suf) suf = t;
+        }
+        u32 after = (u32)__shfl_down((int)suf, 1, 64);          // over the pairs after this lane's
+        if (lane == 63) after = 0xffffffffu;
+        const u32 a1 = after < total ? after : total;
+        sm.nexth[2 * lane + 1] = a1;
+        sm.nexth[2 * lane] = f1 < a1 ? f1 : a1;
+        const u32 m = (u32)__builtin_amdgcn_readlane((int)in2, 63);
+        const u64 excl = lookback_exclusive(a.status, tile, (u64)m, a.epoch, a.err);
+        if (lane == 0) {
+            sm.heads = m;
+            sm.gbase = excl;
+            if (tile == a.tiles - 1) *a.d_total = excl + m;
+            if (excl + m > a.cap) atomicOr(a.err, ZK_DERR_CAPACITY);
+        }
+    }
+    __syncthreads();
+    const u64 gbase = sm.gbase;
+    if (gbase + sm.heads > a.cap) return;
+    // ---- one word per run ---------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const u32 s = (u32)i * BLOCK + tid;
+        const u32 q = (u32)i * NW + wave;
+        const u64 m = sm.mask[q];
+        const u64 rest = (lane < 63) ? (m >> (lane + 1)) : 0ull;
+        const u32 nx = rest ? s + 1 + (u32)__builtin_ctzll(rest) : sm.nexth[q];
+        const u32 j = sm.hbase[q] + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+        if ((headbits >> i) & 1u) a.out[gbase + j] = (key[i] << a.pack) | (u64)(nx - s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // The same pass as a persistent, two-stage pipeline (array source, keys only).
 //
 // Measured on the one-tile-per-workgroup kernel: a tile spends a third of its life in the look-back,
@@ -1367,6 +1559,40 @@ int sort_pairs_mirrored(zk_ctx* c, const u64* src_k, const u32* src_v, u64* keys
 // digit width of the geometry used for key arrays (the truncated sort sizes its bit range with it)
 int sort_rbits(zk_ctx* c) {
     switch (c->sort_variant) { case 0: case 1: case 5: return 8; default: return 9; }
+}
+
+// width of the first digit of sort_keys_upper(key_bits, lo_bit) -- collapse_pass must group by exactly that digit
+int sort_first_bits(zk_ctx* c, int key_bits, int lo_bit) {
+    if (lo_bit >= key_bits) return 0;
+    return make_plan(key_bits - lo_bit, sort_rbits(c), lo_bit).bits[0];
+}
+
+// keys[0..n) ordered by their low `shift` bits -> out[0..*n_out): one word (key << pack | run length) per run of equal keys
+// inside a tile grouped by the digit [shift, shift + bits); max_tiles > 0: only the leading tiles, at most that many (the
+// sample).  2^pack must exceed 512 (run pieces are cut at 512 when 2^pack <= 8192).
+int collapse_pass(zk_ctx* c, const u64* keys, uint64_t n, int shift, int bits, int pack, u64* out, uint64_t cap, uint64_t* n_out,
+                  uint64_t max_tiles) {
+    *n_out = 0;
+    if (n == 0) return ZK_OK;
+    if (bits < 1 || bits > 9 || pack < 10 || pack > 31) return fail(c, ZK_EINTERNAL, "collapse_pass: bits %d, pack %d", bits, pack);
+    CollapseArgs a = {};
+    constexpr uint64_t TILE = CollapseSmem<9>::TILE;
+    uint64_t tiles = div_up(n, TILE);
+    if (max_tiles && tiles > max_tiles) { tiles = max_tiles; n = tiles * TILE; }
+    a.kin = keys; a.n = n; a.out = out; a.cap = cap; a.shift = shift; a.bits = bits; a.pack = pack;
+    a.split = (1u << pack) <= (u32)TILE;
+    a.tiles = (u32)tiles;
+    ZK_TRY(lookback_begin(c, tiles, (u32)tiles, &a.epoch, &a.ticket_base));
+    a.status = c->status; a.ticket = c->d_ticket; a.err = c->d_err; a.d_total = c->d_scalars + 9;
+    prof_begin(c, ZK_PROF_RLE, 8 * n);
+    if (bits <= 8) hipLaunchKernelGGL(collapse_kernel<8>, dim3((u32)tiles), dim3(512), 0, c->stream, a);
+    else hipLaunchKernelGGL(collapse_kernel<9>, dim3((u32)tiles), dim3(512), 0, c->stream, a);
+    prof_end(c);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, c->d_scalars + 9, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_TRY(check_device_error(c));
+    *n_out = c->h_scalars[9];
+    return ZK_OK;
 }
 
 int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,
