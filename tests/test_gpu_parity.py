@@ -405,6 +405,22 @@ def test_kmerize_even_K_palindromes_vs_oracle(ctx, K):
         assert np.array_equal(k.to_host(), want["kmers"]) and np.array_equal(c.to_host(), want["counts"])
 
 
+@pytest.mark.parametrize("K", [1, 2, 13, 25, 31, 32])
+def test_stream_checksum_is_an_independent_encoder(ctx, K):
+    """zk_stream_checksum -- the checker behind every full-size run -- walks the stream byte by byte with the reference's
+    rolling state (basics.kmersList) and shares no code with the product's tile encoder.  Against the oracle's k-mer lists:
+    sums of 1, x and murmer(x) over both strands, and the acgt counts; reads shorter than K, N runs, lower case and U,
+    pieces that start inside a read (128 bytes per thread)."""
+    reads = synth.read_strings(5, 0, 1500, 131, genome=0, n_thr=synth.frac32(0.02))
+    reads += ["", "A", "ACGT", "acgun" * 30, "N" * 200, "T" * 300, "ACGTTGCA" * 40, "GATTACA"]
+    xs = np.concatenate([zo.kmers_list(K, r, True) for r in reads] + [np.zeros(0, dtype=np.uint64)])
+    M = (1 << 64) - 1
+    want = [len(xs), int(xs.sum(dtype=np.uint64)), sum(zo.murmer(int(x), 0) for x in xs) & M]
+    want += [int(np.sum((xs & np.uint64(3)) == np.uint64(b))) for b in range(4)]
+    d = ctx.upload_stream(stream_of(reads))
+    assert [int(v) for v in ctx.stream_checksum(d, K)] + ctx.stream_acgt(d, K) == want
+
+
 def test_kmerize_large_properties(ctx):
     """2 M reads x 150 bp: too big for the fixtures; checked through order-free checksums taken straight
     from the stream, sortedness, strand symmetry, and agreement of the two sort strategies."""

@@ -72,24 +72,42 @@ __global__ void checksum_kernel(const u64* __restrict__ k, const u32* __restrict
     if ((threadIdx.x & 63) == 0) { atomicAdd(&sums[0], s0); atomicAdd(&sums[1], s1); atomicAdd(&sums[2], s2); }
 }
 
-constexpr int CS_BLOCK = 256, CS_ITEMS = 8, CS_TILE = CS_BLOCK * CS_ITEMS;
-__global__ __launch_bounds__(CS_BLOCK) void stream_checksum_kernel(const u8* __restrict__ stream, u64 n_bytes, int K, u32 tiles, u64* sums) {
-    __shared__ TileImage<CS_TILE> img;
+// The checker of the full-size runs (bench.py, tools/verify_k.py) shares NOTHING with the product's encoder
+// (encode_tile.hpp: 2-bit tile images, funnel-shift windows, revcomp by bit tricks): a thread walks its own piece of the
+// stream byte by byte with the reference's rolling state -- forward k-mer shifted left, reverse complement shifted right,
+// a run counter that any non-base byte resets (library/basics.py:303-347) -- after a warm-up of K - 1 bytes before the piece.
+constexpr int CS_BLOCK = 256, CS_SEG = 128;
+__device__ __forceinline__ u32 cs_code(u32 ch) {
+    switch (ch) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': case 'U': case 'u': return 3;
+        default: return 4;
+    }
+}
+__global__ __launch_bounds__(CS_BLOCK) void stream_checksum_kernel(const u8* __restrict__ stream, u64 n_bytes, int K, u64* sums) {
     u64 s0 = 0, s1 = 0, s2 = 0;
     u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    for (u32 tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        stage_tile<CS_BLOCK, CS_TILE>(stream, n_bytes, (u64)tile * CS_TILE, img);
-#pragma unroll
-        for (int i = 0; i < CS_ITEMS; i++) {
-            u64 x;
-            if (window_at(img, (int)threadIdx.x + i * CS_BLOCK, K, x)) {
-                const u64 xb = revcomp(K, x);
-                s0 += 2; s1 += x + xb; s2 += murmer(x, 0) + murmer(xb, 0);
-                const u32 f = (u32)(x & 3), b = (u32)(xb & 3);
-                a0 += (f == 0) + (b == 0); a1 += (f == 1) + (b == 1); a2 += (f == 2) + (b == 2); a3 += (f == 3) + (b == 3);
+    const u64 mask = (K < 32) ? ((1ull << (2 * K)) - 1) : ~0ull;
+    const int top = 2 * (K - 1);
+    for (u64 start = ((u64)blockIdx.x * CS_BLOCK + threadIdx.x) * CS_SEG; start < n_bytes; start += (u64)gridDim.x * CS_BLOCK * CS_SEG) {
+        const u64 end = (start + CS_SEG < n_bytes) ? start + CS_SEG : n_bytes;
+        u64 p = (start >= (u64)(K - 1)) ? start - (u64)(K - 1) : 0;
+        u64 fwd = 0, rev = 0;
+        u32 run = 0;
+        for (; p < end; p++) {
+            const u32 b = cs_code(stream[p]);
+            if (b > 3) { fwd = rev = 0; run = 0; continue; }
+            fwd = ((fwd << 2) | b) & mask;
+            rev = (rev >> 2) | ((u64)(3 - b) << top);
+            run++;
+            if (run >= (u32)K && p >= start) {
+                s0 += 2; s1 += fwd + rev; s2 += murmer(fwd, 0) + murmer(rev, 0);
+                const u32 f = (u32)(fwd & 3), r = (u32)(rev & 3);
+                a0 += (f == 0) + (r == 0); a1 += (f == 1) + (r == 1); a2 += (f == 2) + (r == 2); a3 += (f == 3) + (r == 3);
             }
         }
-        __syncthreads();
     }
     s0 = wave_sum_u64(s0); s1 = wave_sum_u64(s1); s2 = wave_sum_u64(s2);
     const u64 t0 = wave_sum_u64(a0), t1 = wave_sum_u64(a1), t2 = wave_sum_u64(a2), t3 = wave_sum_u64(a3);
@@ -347,8 +365,7 @@ int zk_stream_checksum(zk_ctx* c, const uint8_t* d_stream, uint64_t n_bytes, int
     u64* d = c->d_scalars + 12;
     ZK_HIP(c, hipMemsetAsync(d, 0, 7 * sizeof(u64), c->stream));
     if (n_bytes) {
-        const u32 tiles = (u32)div_up(n_bytes, CS_TILE);
-        hipLaunchKernelGGL(stream_checksum_kernel, dim3(grid_for(c, tiles, 1)), dim3(CS_BLOCK), 0, c->stream, d_stream, (u64)n_bytes, K, tiles, d);
+        hipLaunchKernelGGL(stream_checksum_kernel, dim3(grid_for(c, n_bytes, (u64)CS_BLOCK * CS_SEG)), dim3(CS_BLOCK), 0, c->stream, d_stream, (u64)n_bytes, K, d);
         ZK_HIP(c, hipGetLastError());
     }
     ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 12, d, 7 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
