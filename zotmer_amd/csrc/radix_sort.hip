@@ -1088,11 +1088,16 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
     for (;;) {
         if (!vB && !have) break;
         if (vB) PSTAMP(tB, 0);
+        // opaque per iteration: the 64-bit addresses built from the thread index (status row, histogram row, key base) are
+        // then recomputed where they are used instead of living -- or being spilled -- across the whole tile loop
+        u32 tid_o = (u32)tid;
+        asm volatile("" : "+v"(tid_o));
         u64 key[ITEMS];
         u32 rank2[ITEMS / 2];          // two 16-bit ranks per register
         u32 live = 0;
         u32 tC = 0;
         bool vC = false;
+        bool early = false;          // the next tile's keys were asked for before tile A's stores
         u32 tcB[DPT], dexB[DPT];
         u32 incB = 0, tsumB = 0;
         u64 rowA[DPT];
@@ -1139,7 +1144,11 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                 __syncthreads();      // the image is dead: its space becomes the counters
             }
             // this wave's counters: private to the wave until the scan, so no barrier after zeroing them
-            for (int q = lane; q < RADIX / 8; q += 64) reinterpret_cast<uint4*>(mycnt)[q] = make_uint4(0, 0, 0, 0);
+            {
+                u32 z = 0;          // made here, not kept: a zero quad held (or spilled) across the tile loop costs four registers
+                asm volatile("" : "+v"(z));
+                for (int q = lane; q < RADIX / 8; q += 64) reinterpret_cast<uint4*>(mycnt)[q] = make_uint4(z, z, z, z);
+            }
 #ifdef ZK_STAMPS
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -1158,6 +1167,12 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                 if (lv && below == npeer - 1) mycnt[d] = (u16)(pre + npeer);
             }
             PSTAMP(tB, 2);
+            // the digits are recomputed when the tile is parked (two instructions each) instead of sixteen more registers
+            // staying live across tile A's stores -- room for the next tile's keys to be in flight by then
+            if constexpr (SRC == SRC_ARRAY) {
+#pragma unroll
+                for (int i = 0; i < ITEMS; i++) asm volatile("" : "+v"(key[i]));
+            }
             // the atomic was issued before this tile's key loads, so it has returned by now (no extra wait)
             if (tid == 0) {
                 u32 t = tile_of(myx, pending, a.nx, a.glog);
@@ -1167,13 +1182,23 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
             if (have) {
 #pragma unroll
                 for (int j = 0; j < DPT; j++) {
-                    const int d = tid * DPT + j;
+                    const int d = (int)tid_o * DPT + j;
                     if (d < RADIX) rowA[j] = ld_agent(a.status + (u64)tileA * RADIX + d);   // consumed after B is published
                 }
             }
             __syncthreads();
             tC = (u32)__builtin_amdgcn_readfirstlane((int)sm.ticket);
             vC = tC < tiles;
+            if constexpr (SRC == SRC_ARRAY) {
+                early = vC && (u64)(tC + 1) * TILE <= a.n;          // whole tiles only: one load path, no join
+                if (early) {
+                    if (tid == 0) pending = atomicAdd(a.xticket + 32 * myx, 1u);
+                    const u64* p = a.kin + (u64)tC * TILE + (u64)(wave * (64 * ITEMS) + (int)(tid_o & 63u));
+#pragma unroll
+                    for (int i = 0; i < ITEMS; i++) nx.key[i] = p[i * 64];
+                    nx.live = (1u << ITEMS) - 1u;
+                }
+            }
             // ---- per digit: scan over the waves, publish the tile's count at once -------------------
             u32 tsum = 0;
 #pragma unroll
@@ -1203,7 +1228,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
             // ---- tile A: offsets, then out of LDS ------------------------------------------------
 #pragma unroll
             for (int j = 0; j < DPT; j++) {
-                const int d = tid * DPT + j;
+                const int d = (int)tid_o * DPT + j;
                 if (d < RADIX) {
                     const u64* q = a.status + (u64)tileA * RADIX + d;
                     u64 w = vB ? rowA[j] : ld_agent(q);
@@ -1248,7 +1273,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
             asm volatile("" : "+v"(slot0));
             // eight slots at a time: the LDS reads of a group are independent of each other (slots past the live
             // count hold stale but readable keys), only the global store is predicated
-            constexpr int G = 4;
+            constexpr int G = (SRC == SRC_ARRAY) ? 2 : 4;
 #pragma unroll
             for (int i0 = 0; i0 < ITEMS; i0 += G) {
                 u64 kk[G], pos[G];
@@ -1280,11 +1305,26 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
         have = true;
         tB = tC;
         vB = vC;
-        // Loading C any earlier (while B's keys and ranks are live) costs more in spilled registers than
-        // the hidden latency gives back (measured: 2.87 vs 3.13 TB/s), so the loads start here.
-        if (vB) {
+        // Array source: a whole tile C was asked for right after B was ranked (above) -- that fits the 128 registers only
+        // because the digits, the thread-index addresses and the zero quad are NOT kept across the iteration (the opaque
+        // copies above; before, 16 early rows spilled and 4 were slower than none).  Worth 2 % of the pass.
+        // Stream source and the cut last tile: the loads start here.
+        if (vB && !early) {
             if (tid == 0) pending = atomicAdd(a.xticket + 32 * myx, 1u);
-            issue_loads(tB);
+            if constexpr (SRC == SRC_ARRAY) {
+                // only the cut last tile comes here: per-key bounds
+                const u64 base = (u64)tB * TILE + (u64)wave * (64 * ITEMS) + lane;
+                nx.live = 0;
+#pragma unroll
+                for (int i = 0; i < ITEMS; i++) {
+                    const u64 idx = base + (u64)i * 64;
+                    const bool ok = idx < a.n;
+                    nx.key[i] = ok ? a.kin[idx] : 0ull;
+                    nx.live |= (ok ? 1u : 0u) << i;
+                }
+            } else {
+                issue_loads(tB);
+            }
         }
     }
 }
