@@ -425,6 +425,8 @@ def main():
     flags = native.KMERIZE_BOTH if a.both else native.KMERIZE_CANONICAL
 
     ctx = native.Context(local)
+    if os.environ.get("ZOT_TUNE"):          # A/B runs of the library's knobs, e.g. ZOT_TUNE=wide_tiles=0,early_collapse=2 (recorded in the line)
+        ctx.tune(**{k: int(v) for k, v in (kv.split("=") for kv in os.environ["ZOT_TUNE"].split(","))})
     if a.only_extra:
         fn = {"config3_dist": lambda: extra_config3(ctx, 5, a.extras_scale),
               "config4_merge_share": lambda: extra_config4_share(ctx, 3, a.extras_scale),
@@ -554,6 +556,7 @@ def main():
                                    % (K, R, L),
                        "reads_per_gpu": R, "read_len": L, "K": K, "genome": cfg["genome"], "seed": seed,
                        "strategy": "both-strands" if a.both else "canonical+mirror",
+                       **({"tune": os.environ["ZOT_TUNE"]} if os.environ.get("ZOT_TUNE") else {}),
                        "parallelism": "1 gpu" if world == 1 else "reads sharded over %d gpus + %s-owner all-to-all (%s)"
                                       % (world, par.owner, par.comm.name)},
             "roofline": {"bound": "hbm", "kernel": "pass_pipe_kernel<array,keys> (one LSD radix pass of 64-bit keys, 16 B/key, persistent two-stage pipeline)",

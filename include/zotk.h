@@ -74,6 +74,7 @@ int zk_upload_async(zk_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 #define ZK_TUNE_EARLY_COLLAPSE 7 /* zk_kmerize: 1 (default) = count runs after the low-bit sort passes and finish the sort on (k-mer, count) pairs,
                                     the count fused into the last of those passes when the pairs pack into one word; 2 = never fused; 0 = off */
 #define ZK_TUNE_PACKED_PAIRS 8   /* zk_kmerize / zk_mirror_expand: 1 (default) = (k-mer, count) pairs travel as one 64-bit word when the counts fit the bits above 2K */
+#define ZK_TUNE_WIDE_TILES 9     /* radix sort: 1 (default) = array passes over up to 3 * 2^30 keys use 16 K-key tiles, one workgroup per CU */
 #define ZK_TUNE_COMM_CHUNK 6     /* zk_all_to_all_v: bytes per message and round (0 = 256 MiB, the default) */
 int zk_tune(zk_ctx* ctx, int what, int value);
 

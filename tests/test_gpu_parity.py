@@ -103,7 +103,7 @@ def test_sort_keys(ctx, n, bits):
     assert np.array_equal(got, np.sort(x))
 
 
-@pytest.mark.parametrize("variant", range(6))
+@pytest.mark.parametrize("variant", range(7))
 def test_sort_keys_every_geometry(ctx, variant):
     """every instantiated tile geometry / look-back scheme (zk_tune): same result, stable for pairs"""
     try:

@@ -19,6 +19,7 @@ struct zk_ctx {
                                // pays off on uncorrelated reads only)
     int packed_pairs = 1;      // (k-mer, count) pairs travel as ONE word (k-mer << s | count) through the key kernel when the counts fit the
                                // spare bits above 2K (pipeline.hip); zk_tune, tests
+    int wide_tiles = 1;        // radix sort, default geometry: smaller array passes on 16 K-key tiles, one workgroup per CU (radix_sort.hip V6)
     int early_collapse = 1;    // zk_kmerize (canonical): run-length count after the low-bit passes, finish the sort on pairs (pipeline.hip);
                                // 1 = counted inside the tile-local ranking of the last of those digits (collapse_kernel) when the pairs pack,
                                // 2 = always as a pass of its own

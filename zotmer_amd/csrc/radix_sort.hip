@@ -1332,6 +1332,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
+int launch_wide_pass(zk_ctx* c, const SortArgs& a);
+constexpr u64 WIDE_TILES_MAX_KEYS = 3ull << 30;
+
 template <class C>
 struct Sorter {
     static u32 tiles_for(const SortArgs& a, int src) {
@@ -1370,7 +1373,7 @@ struct Sorter {
       if constexpr (C::PIPE) {
         const u32 tiles = tiles_for(a, SRC);
         if (tiles == 0) return ZK_OK;
-        u32 grid = (u32)c->num_cus * 2;
+        u32 grid = (u32)c->num_cus * (sizeof(PipeSmem<C>) > 80 * 1024 ? 1 : 2);          // what fits a CU's 160 KB of LDS
         if (grid > tiles) grid = tiles;
         grid += C::RADIX / 64;          // the scanner workgroups
         ZK_TRY(lookback_begin(c, (uint64_t)tiles * C::RADIX, grid, &a.epoch, &a.ticket_base));   // one role ticket per workgroup
@@ -1397,6 +1400,9 @@ struct Sorter {
       return ZK_OK;
     }
     static int launch_keys_pass(zk_ctx* c, const SortArgs& a) {
+        // the default geometry hands its array passes to the 16 K-key tiles (same digits, same histograms) while the array is
+        // not too big for them: see V6
+        if constexpr (C::PIPE && C::RBITS == 9 && C::BLOCK == 512) { if (c->wide_tiles && a.n <= WIDE_TILES_MAX_KEYS) return launch_wide_pass(c, a); }
         if (C::PIPE) return launch_pipe<SRC_ARRAY>(c, a);
         return launch_pass<SRC_ARRAY, false>(c, a);
     }
@@ -1551,6 +1557,12 @@ typedef Cfg<512, 16, 9, 1, 4, 0> V2;
 typedef Cfg<512, 16, 9, 1, 4, 32, true> V3;
 typedef Cfg<512, 16, 9, 1, 4, 32> V4;
 typedef Cfg<512, 16, 8, 1, 4, 32, true> V5;      // the pipeline with 8-bit digits: 256-byte runs, 7 passes
+// 6: the pipeline with 16 K-key tiles, one 1024-thread workgroup per CU (150 KB LDS): a digit gets 32 keys = 256 bytes per tile
+//    instead of 128 -- 3.78 vs 3.42 TB/s per pass at 2 x 10^9 keys, 3.62 vs 4.15 ms at 0.9 x 10^9, but 30.1 vs 28.0 ms at
+//    6.2 x 10^9 (one workgroup per CU: nothing else runs while it stores).  The default (3) uses it for array passes of up to
+//    3 x 2^30 keys (zk_tune ZK_TUNE_WIDE_TILES, on); pass 0 from the stream keeps the 8 K-key tiles.
+typedef Cfg<1024, 16, 9, 1, 4, 32, true> V6;
+int launch_wide_pass(zk_ctx* c, const SortArgs& a) { return Sorter<V6>::launch_pipe<SRC_ARRAY>(c, a); }
 #define ZK_SORT_DISPATCH(c, CALL) ZK_SORT_DISPATCH_V((c)->sort_variant, CALL)
 #define ZK_SORT_DISPATCH_V(v, CALL)                 \
     switch (v) {                                    \
@@ -1559,6 +1571,7 @@ typedef Cfg<512, 16, 8, 1, 4, 32, true> V5;      // the pipeline with 8-bit digi
         case 2: return Sorter<V2>::CALL;            \
         case 4: return Sorter<V4>::CALL;            \
         case 5: return Sorter<V5>::CALL;            \
+        case 6: return Sorter<V6>::CALL;            \
         default: return Sorter<V3>::CALL;           \
     }
 
