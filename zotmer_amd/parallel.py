@@ -583,6 +583,24 @@ def make_comm(ctx, dist, notes=None):
         comm.all_to_all_v(dst, src, [4] * W, [4] * W, [4 * i for i in range(W + 1)], [4 * i for i in range(W + 1)])
         want_t = torch.cat([torch.arange(4 * r, 4 * r + 4, dtype=torch.int64, device="cuda") + 1000 * q for q in range(W)])
         ok = bool(torch.equal(dst, want_t)) and comm.all_reduce([r + 1, 1 << 40]) == [W * (W + 1) // 2, (W << 40) & M64]
+        if ok:
+            # ragged pieces, empty ones among them, in rounds of 16 bytes: the paths a real exchange takes (peers that send
+            # nothing, a last partial round) and the uniform probe above does not
+            cnt = lambda a, b: (7 * a + 3 * b) % 6                                      # noqa: E731 -- elements rank a sends to rank b
+            send, recv = [cnt(r, q) for q in range(W)], [cnt(q, r) for q in range(W)]
+            so, ro = [0] + list(np.cumsum(send)), [0] + list(np.cumsum(recv))
+            src = torch.cat([torch.arange(send[q], dtype=torch.int64, device="cuda") + 100 * q + 10000 * r for q in range(W)] +
+                            [torch.zeros(1, dtype=torch.int64, device="cuda")])
+            dst = torch.full((int(ro[-1]) + 1,), -1, dtype=torch.int64, device="cuda")
+            want_t = torch.cat([torch.arange(recv[q], dtype=torch.int64, device="cuda") + 100 * r + 10000 * q for q in range(W)] +
+                               [torch.full((1,), -1, dtype=torch.int64, device="cuda")])
+            torch.cuda.synchronize()
+            ctx.tune(comm_chunk=16)
+            try:
+                comm.all_to_all_v(dst, src, recv, send, [int(v) for v in so], [int(v) for v in ro])
+            finally:
+                ctx.tune(comm_chunk=0)
+            ok = bool(torch.equal(dst, want_t))
         if not ok:
             why = "probe exchange returned wrong data"
     except Exception as e:       # noqa: BLE001 -- any failure of the optional transport selects the other one, on every rank
