@@ -71,8 +71,9 @@ int zk_upload_async(zk_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 #define ZK_TUNE_SHORT_SORT 3     /* zk_kmerize: 1 = sort only the top ~log2(n)+3 bits, finish in the mirror stage (default 0) */
 #define ZK_TUNE_XCD_GROUP 5    /* radix-sort pipeline: runs of this many consecutive tiles go to one XCD (0 = off, the default; <= 32) */
 #define ZK_TUNE_SIDE_DIV 4       /* ... side-list capacity = n / value (default 8); overflow falls back to the full sort */
-#define ZK_TUNE_EARLY_COLLAPSE 7 /* zk_kmerize: 1 (default) = count runs after the low-bit sort passes and finish the sort on (k-mer, count) pairs,
-                                    the count fused into the last of those passes when the pairs pack into one word; 2 = never fused; 0 = off */
+#define ZK_TUNE_EARLY_COLLAPSE 7 /* zk_kmerize: count the copies of a k-mer before the sort is finished and finish it on (k-mer, count) words:
+                                    1 (default) = as early as possible (block hash tables, else tile-local ranking), 3 = tile-local ranking only,
+                                    2 = a run-length pass of its own once the copies are neighbours, 0 = off */
 #define ZK_TUNE_PACKED_PAIRS 8   /* zk_kmerize / zk_mirror_expand: 1 (default) = (k-mer, count) pairs travel as one 64-bit word when the counts fit the bits above 2K */
 #define ZK_TUNE_WIDE_TILES 9     /* radix sort: 1 (default) = array passes over up to 3 * 2^30 keys use 16 K-key tiles, one workgroup per CU */
 #define ZK_TUNE_COMM_CHUNK 6     /* zk_all_to_all_v: bytes per message and round (0 = 256 MiB, the default) */

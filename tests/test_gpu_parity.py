@@ -299,8 +299,9 @@ def test_kmerize_early_collapse_paths_agree(ctx, K):
     """zk_kmerize (canonical) counts runs after the passes over the low bits and finishes the sort on (k-mer, count) pairs when a
     sample says the reads repeat their k-mers; otherwise the keys finish the sort.  Both ways, and with the collapse switched
     off, the arrays must be the oracle's -- also when distinct k-mers share all their low bits, so that their copies interleave
-    and the final reduce has to add up split runs.  early_collapse = 1 counts the runs inside the tile-local ranking of the last
-    low digit (collapse_kernel: K <= 27, where a pair packs into one word; K = 26, 27 have fewer than 14 spare bits, so long runs
+    and the final reduce has to add up split runs.  early_collapse = 1 counts in LDS hash tables over blocks of equal low bits
+    (dedupe_kernel; counts beyond the packed field go out as several words), 3 inside the tile-local ranking of the last low
+    digit (collapse_kernel: K <= 27, where a pair packs into one word; K = 26, 27 have fewer than 14 spare bits, so long runs
     are cut every 512 slots), 2 as a pass of its own."""
     rng = np.random.default_rng(100 + K)
     deep = synth.read_strings(11, 0, 6000, 150, genome=12000, sub_thr=synth.frac32(0.004), n_thr=synth.frac32(0.001))   # ~60x: collapses
@@ -316,7 +317,7 @@ def test_kmerize_early_collapse_paths_agree(ctx, K):
         want = zo.kmerize(K, reads)
         d = ctx.upload_stream(stream_of(reads))
         try:
-            for on, packed in ((1, 1), (2, 1), (1, 0), (0, 1), (0, 0)):
+            for on, packed in ((1, 1), (3, 1), (2, 1), (1, 0), (0, 1), (0, 0)):
                 ctx.tune(early_collapse=on, packed_pairs=packed)
                 k, c, st = ctx.kmerize(d, K)
                 assert np.array_equal(k.to_host(), want["kmers"]), (name, on, packed)
@@ -422,9 +423,10 @@ def test_stream_checksum_is_an_independent_encoder(ctx, K):
 
 
 def test_kmerize_large_properties(ctx):
-    """2 M reads x 150 bp: too big for the fixtures; checked through order-free checksums taken straight
-    from the stream, sortedness, strand symmetry, and agreement of the two sort strategies."""
-    R, L, K = 2_000_000, 150, 25
+    """4.1 M reads x 150 bp: too big for the fixtures; checked through order-free checksums taken straight
+    from the stream, sortedness, strand symmetry, and agreement of the sort strategies.  At this size (> 2^29 stream bytes) the
+    default path is the block dedupe after two passes with 32-bit table entries, as on BASELINE config 2."""
+    R, L, K = 4_100_000, 150, 25
     d = ctx.synth_reads(synth.DEFAULT_SEED, 0, R, L, genome=4_000_000, sub_thr=synth.frac32(0.005), n_thr=synth.frac32(0.0005))
     want = ctx.stream_checksum(d, K)
     k, c, st = ctx.kmerize(d, K, native.KMERIZE_CANONICAL, cap=3 * R * (L - K + 1) // 2)
@@ -440,10 +442,11 @@ def test_kmerize_large_properties(ctx):
     k2, c2, st2 = ctx.kmerize(d, K, native.KMERIZE_BOTH, cap=len(kh) + 16)
     assert np.array_equal(k2.to_host(), kh) and np.array_equal(c2.to_host(), ch)
     assert list(st2.acgt) == list(st.acgt)
-    ctx.tune(early_collapse=0)                   # the plain full-width sort of the canonical keys
     try:
-        k4, c4, _ = ctx.kmerize(d, K, native.KMERIZE_CANONICAL, cap=len(kh) + 16)
-        assert np.array_equal(k4.to_host(), kh) and np.array_equal(c4.to_host(), ch)
+        for mode in (3, 2, 0):                   # tile-local ranking; run-length pass of its own; the plain full-width sort
+            ctx.tune(early_collapse=mode)
+            k4, c4, _ = ctx.kmerize(d, K, native.KMERIZE_CANONICAL, cap=len(kh) + 16)
+            assert np.array_equal(k4.to_host(), kh) and np.array_equal(c4.to_host(), ch), mode
     finally:
         ctx.tune(early_collapse=1)
     # the same reads through the oracle on a 20 000-read prefix

@@ -20,9 +20,10 @@ struct zk_ctx {
     int packed_pairs = 1;      // (k-mer, count) pairs travel as ONE word (k-mer << s | count) through the key kernel when the counts fit the
                                // spare bits above 2K (pipeline.hip); zk_tune, tests
     int wide_tiles = 1;        // radix sort, default geometry: smaller array passes on 16 K-key tiles, one workgroup per CU (radix_sort.hip V6)
-    int early_collapse = 1;    // zk_kmerize (canonical): run-length count after the low-bit passes, finish the sort on pairs (pipeline.hip);
-                               // 1 = counted inside the tile-local ranking of the last of those digits (collapse_kernel) when the pairs pack,
-                               // 2 = always as a pass of its own
+    int early_collapse = 1;    // zk_kmerize (canonical): count the copies before the sort is finished, finish it on (k-mer, count) words
+                               // (pipeline.hip): 1 = as early as possible (dedupe_kernel after the passes that leave blocks of <= 32 K keys,
+                               // else collapse_kernel one pass before the copies are neighbours), 3 = collapse_kernel only,
+                               // 2 = a run-length pass of its own once the copies are neighbours (the round's first form), 0 = off
     int side_div = 8;          // ... side list capacity = n / side_div (tests shrink it to force the fallback)
     int pairs_variant = 2;     // ... for (key, u32) pairs
 
@@ -120,6 +121,8 @@ int sort_pairs_mirrored(zk_ctx* c, const u64* src_k, const u32* src_v, u64* keys
 struct StreamSrc { const u8* stream; uint64_t n_bytes; int K; int mode; int lo_bit; int hi_bit = 0; };   // mode: ZK_KEYS_*; sort bits [lo_bit, hi_bit) (hi_bit 0 = 2K)
 int sort_rbits(zk_ctx* c);
 int sort_first_bits(zk_ctx* c, int key_bits, int lo_bit);
+int dedupe_pass(zk_ctx* c, u64* keys, uint64_t n, int key_bits, int shift, int pack, u64* work, uint64_t cap, u64** result,
+                uint64_t* n_out, uint32_t* flags, uint64_t* n_in = nullptr, uint64_t max_chunks = 0);
 int collapse_pass(zk_ctx* c, const u64* keys, uint64_t n, int shift, int bits, int pack, u64* out, uint64_t cap, uint64_t* n_out,
                   uint64_t max_tiles = 0);
 int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,

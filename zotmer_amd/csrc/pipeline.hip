@@ -228,9 +228,19 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     if (!both && c->early_collapse) {
         const int b = rb * ((ilog2_ceil(n_bytes) + 3 + rb - 1) / rb);
         if (b + rb / 2 < 2 * K) collapse_bit = b;
-        if (collapse_bit >= 2 * rb && c->early_collapse == 1 && c->packed_pairs && pack_bits_for(K)) fused_bit = collapse_bit - rb;
+        if (collapse_bit >= 2 * rb && (c->early_collapse == 1 || c->early_collapse == 3) && c->packed_pairs && pack_bits_for(K)) fused_bit = collapse_bit - rb;
     }
-    src.hi_bit = fused_bit ? fused_bit : collapse_bit;
+    // One pass earlier still while the blocks of keys that share their sorted low bits are small enough for an LDS hash table
+    // (dedupe_kernel: at most 32 K keys per block by the stream's length, at least 2 K so that the copies of a k-mer are spread
+    // over many wavefronts): config 2 is counted after TWO passes.
+    int dedupe_bit = 0;
+    if (fused_bit && c->early_collapse == 1) {
+        const int lg = ilog2_ceil(n_bytes);
+        const int passes = lg > 15 ? (lg - 15 + rb - 1) / rb : 1;
+        const int b = rb * passes;
+        if (b < fused_bit + rb && b + rb / 2 < 2 * K && b <= 24 && (n_bytes >> b) >= 2048) dedupe_bit = b;
+    }
+    src.hi_bit = dedupe_bit ? dedupe_bit : (fused_bit ? fused_bit : collapse_bit);
     uint64_t n = 0;
     u64* sorted = nullptr;
     ZK_TRY(sort_stream(c, src, buf_a, buf_b, cap_keys, &n, st->acgt, &sorted));
@@ -247,6 +257,41 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     bool in_aux = false;          // the counted list lives in the aux region (collapse path): both sort buffers are free
     uint64_t max_count = 0;       // largest count of the list, when it came for free (packed reduce)
     bool have_max = false;
+    if (dedupe_bit && n) {
+        const int pk = pack_bits_for(K);
+        uint64_t us = 0, u1 = 0, n_in = 0;
+        uint32_t fl = 0;
+        bool done = false;
+        // the sample: the leading blocks, about a million keys
+        const uint64_t nblocks = 1ull << dedupe_bit, per = n / nblocks + 1;
+        u64* words = nullptr;
+        ZK_TRY(dedupe_pass(c, sorted, n, 2 * K, dedupe_bit, pk, other, cap_keys, &words, &us, &fl, &n_in, (1u << 20) / per + 1));
+        if (!fl && (double)us <= 0.6 * (double)n_in) {
+            ZK_TRY(dedupe_pass(c, sorted, n, 2 * K, dedupe_bit, pk, other, cap_keys, &words, &u1, &fl));
+            if (!fl) {
+                u64* res = nullptr;
+                ZK_TRY(sort_keys_upper(c, words, other, u1, 2 * K + pk, dedupe_bit + pk, &res));          // words == sorted: the keys are gone
+                const uint64_t a8 = (8 * u1 + 255) & ~255ull, a4 = (4 * u1 + 255) & ~255ull;
+                char* aux;
+                ZK_TRY(aux_require(c, a8 + a4, &aux));
+                ZK_TRY(reduce_by_key(c, res, nullptr, u1, (u64*)aux, (u32*)(aux + a8), u1, &uc, pk, &max_count));
+                sorted = (u64*)aux; cnt = (u32*)(aux + a8);
+                in_aux = true;
+                have_max = true;
+                done = true;
+            }
+        }
+        if (!done) {
+            // little duplication, or a table filled up: the keys (untouched: the words went to the other buffer) finish the sort
+            u64* res = nullptr;
+            ZK_TRY(sort_keys_upper(c, sorted, other, n, 2 * K, dedupe_bit, &res, ZK_PROF_PASS_KEYS));
+            sorted = res;
+            other = (sorted == buf_a) ? buf_b : buf_a;
+            cnt = (u32*)other;
+        }
+        fused_bit = 0;
+        collapse_bit = 0;
+    }
     if (fused_bit && n) {
         // Runs are counted inside the tile-local ranking of the next digit above fused_bit (radix_sort.hip::collapse_kernel):
         // that pass writes one word per run instead of every key, and no pass of its own reads the keys again to count.  Its

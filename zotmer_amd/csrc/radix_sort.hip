@@ -915,6 +915,224 @@ __global__ __launch_bounds__(512, 4) void collapse_kernel(CollapseArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Block dedupe (zk_kmerize, canonical keys; see pipeline.hip::kmerize_full) -- the collapse one pass earlier still.
+//
+// With the low b bits sorted, ALL copies of a k-mer lie in the block of keys that share those b bits (they share every bit).
+// While such a block is small -- n / 2^b keys; 23.7 K after two passes on config 2 -- it is counted in an LDS hash table:
+// one workgroup per block (2^b of them; boundaries by binary search) claims an entry per distinct key with a 64-bit
+// compare-and-swap, counts copies with an add, and writes one word (key << pack | count) per entry, blocks one after the
+// other.  Every k-mer is then counted completely -- no run is ever cut -- and the words are still ordered by their low b
+// bits (inside a block the order is the table's, which does not matter: they all share those bits), so the LSD passes
+// over the words continue at bit b.  Unlike the tile-local variant (collapse_kernel: copies within a few dozen slots of
+// each other, i.e. in the same 64 lanes, where a table suffers same-address conflicts on every instruction), the copies are
+// spread over the whole block here and the atomics run conflict-free.
+// A count beyond the packed field goes out as several words with the same key (reduce_by_key adds up equal keys after the
+// sort anyway).  A table that fills up (a chunk with more than ~5 K distinct keys: little duplication) raises a flag and the
+// caller takes another path -- the result never depends on the table.
+// ---------------------------------------------------------------------------------------
+// TAG32: the bits of a key above `shift` fit 32 bits (the bits below are the block's number): entries of 4 + 4 bytes, 16 K of them.
+// 12 K / 16 K entries: the blocks are not of one size -- a canonical k-mer more often ends in A than in T (it is the smaller
+// strand), so the block sizes spread from ~0 to 2 x the mean with the last bases; one 1024-thread workgroup per CU.
+template <bool TAG32>
+struct DedupeSmem {
+    static constexpr int BLOCK = 1024, ITEMS = 8, TILE = BLOCK * ITEMS, NW = BLOCK / 64, SLOTS = TAG32 ? 16384 : 12288, SPT = SLOTS / BLOCK,
+                         PROBES = 128;
+    typedef typename std::conditional<TAG32, u32, u64>::type E;
+    E keys[SLOTS];
+    u32 cnt[SLOTS];
+    u32 wsum[NW];
+};
+
+struct DedupeArgs {
+    const u64* kin;
+    u64 n;
+    const u64* cuts;    // [chunks + 1]: chunk v = the block of keys whose low `shift` bits are v
+    u64* out;           // block v writes its words from out + cuts[v] on (never more words than keys); dedupe_pack_kernel closes the gaps
+    u64* nwords;        // [chunks] words of block v
+    int shift;          // b: the keys are ordered by their low b bits
+    int pack;
+    u32* flags;         // |= 1: a table filled up
+    u32 chunks;
+};
+
+// cuts[v] = first index whose low `shift` bits are >= v, v = 0 .. blocks (blocks = 2^shift unless only the leading ones are wanted)
+__global__ void dedupe_cuts_kernel(const u64* __restrict__ k, u64 n, int shift, u32 blocks, u64* __restrict__ cuts) {
+    const u32 v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > blocks) return;
+    const u64 mask = (1ull << shift) - 1;
+    u64 lo = 0, hi = n;
+    if (((u64)v >> shift) != 0) lo = n;          // v = 2^shift: the end
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if ((k[mid] & mask) < (u64)v) lo = mid + 1; else hi = mid;
+    }
+    cuts[v] = lo;
+}
+
+template <bool TAG32>
+__global__ __launch_bounds__(1024, 4) void dedupe_kernel(DedupeArgs a) {
+    using S = DedupeSmem<TAG32>;
+    using E = typename S::E;
+    constexpr int BLOCK = S::BLOCK, ITEMS = S::ITEMS, TILE = S::TILE, NW = S::NW, SLOTS = S::SLOTS, SPT = S::SPT;
+    constexpr E EMPTY = (E)~(E)0;            // no entry: a k-mer leaves `pack` >= 10 high bits zero (TAG32: see insert)
+    __shared__ S sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // No order between the workgroups: a block's words go to the block's own place in the output (its input offset) and
+    // are moved together afterwards -- a chain of output offsets would make the small blocks wait for the big ones before them
+    // (the sizes spread 8 : 1), with one workgroup per CU that is idle silicon.
+    const u32 chunk = blockIdx.x;
+    const u64 lo = a.cuts[chunk], hi = a.cuts[chunk + 1];
+    const u32 maxc = (1u << a.pack) - 1u;
+    if (hi <= lo) {
+        if (tid == 0) a.nwords[chunk] = 0;
+        return;
+    }
+    for (int q = tid; q < SLOTS * (int)sizeof(E) / 16; q += BLOCK) reinterpret_cast<uint4*>(sm.keys)[q] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    for (int q = tid; q < SLOTS / 4; q += BLOCK) reinterpret_cast<uint4*>(sm.cnt)[q] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    u32 bad = 0;
+    // One key after the other, each in the tightest loop there is: everything fancier (several keys probing at once,
+    // store-and-verify rounds instead of the compare-and-swap) cost more instructions than it hid latency -- the kernel is bound
+    // by its instruction count (188 per key in the batched form, 110 in this one before the tags and the whole-tile path).
+    auto insert = [&](u64 k) {
+        E e;
+        u32 x;
+        if constexpr (TAG32) { e = (u32)(k >> a.shift); x = e * 0x9E3779B1u; }
+        else { e = k; x = ((u32)(k >> a.shift) ^ ((u32)k * 0x85EBCA6Bu)) * 0x9E3779B1u; }
+        // TAG32: the tag may use all 32 bits, so the all-ones tag (= the empty marker) has the last entry to itself: it is never
+        // probed, its key word stays all ones, and only its count says whether it is there
+        constexpr u32 HS = TAG32 ? SLOTS - 1 : SLOTS;
+        u32 h = (u32)(((u64)x * HS) >> 32);
+        int p = 0;
+        if (TAG32 && e == EMPTY) h = HS;
+        else
+        for (; p < S::PROBES; p++) {
+            E old;
+            if constexpr (TAG32) old = atomicCAS(&sm.keys[h], EMPTY, e);
+            else old = atomicCAS(reinterpret_cast<unsigned long long*>(&sm.keys[h]), (unsigned long long)EMPTY, (unsigned long long)e);
+            if (old == EMPTY || old == e) break;
+            h = h + 1 == HS ? 0u : h + 1;
+        }
+        if (p < S::PROBES) atomicAdd(&sm.cnt[h], 1u); else bad = 1;
+    };
+    u64 key[ITEMS], nk[ITEMS];
+    // whole tiles: one address, constant offsets; the cut last tile: per-key bounds
+    auto load = [&](u64 base, u64 (&k)[ITEMS]) {
+        if (base + TILE <= hi) {
+            const u64* p = a.kin + base + tid;
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) k[i] = p[i * BLOCK];
+        } else {
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const u64 g = base + (u64)i * BLOCK + tid;
+                k[i] = g < hi ? a.kin[g] : ~0ull;
+            }
+        }
+    };
+    load(lo, key);
+    for (u64 base = lo; base < hi; base += TILE) {
+        if (base + TILE < hi) load(base + TILE, nk);
+        if (base + TILE <= hi) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) insert(key[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++)
+                if (key[i] != ~0ull) insert(key[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) key[i] = nk[i];
+    }
+    if (bad) atomicOr(a.flags, 1u);
+    __syncthreads();
+    // ---- words per entry: thread t owns the entries t, t + BLOCK, ...; one word unless the count exceeds the field ------
+    u32 occ = 0, big = 0;
+#pragma unroll
+    for (int j = 0; j < SPT; j++) {
+        const u32 cj = sm.cnt[tid + j * BLOCK];
+        occ |= (cj ? 1u : 0u) << j;
+        big |= cj > maxc ? 1u : 0u;
+    }
+    const u64 gbase = lo;
+    const u64 low = (u64)chunk;          // TAG32: the bits of every key of the block below `shift`
+    if (!__syncthreads_or((int)big)) {
+        // the usual case: one word per entry -- ballots and bit counts
+        u32 mine = 0;
+#pragma unroll
+        for (int j = 0; j < SPT; j++) mine += (u32)__popcll(__ballot((occ >> j) & 1u));
+        if (lane == 0) sm.wsum[wave] = mine;
+        __syncthreads();
+        u32 j0 = 0, total = 0;
+        for (int w = 0; w < NW; w++) {
+            const u32 t = sm.wsum[w];
+            if (w < wave) j0 += t;
+            total += t;
+        }
+        if (tid == 0) a.nwords[chunk] = total;
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            const bool on = (occ >> j) & 1u;
+            const u64 m = __ballot(on);
+            if (on) {
+                const u32 s = (u32)tid + (u32)j * BLOCK;
+                u64 k;
+                if constexpr (TAG32) k = ((u64)sm.keys[s] << a.shift) | low; else k = sm.keys[s];
+                a.out[gbase + j0 + popc_below(m)] = (k << a.pack) | (u64)sm.cnt[s];
+            }
+            j0 += (u32)__popcll(m);
+        }
+        return;
+    }
+    // some count is beyond the field: it goes out as several words with the same key (reduce_by_key adds them up again)
+    u32 nw[SPT];
+    u32 mine = 0;
+#pragma unroll
+    for (int j = 0; j < SPT; j++) {
+        const u32 cj = sm.cnt[tid + j * BLOCK];
+        nw[j] = cj ? 1u : 0u;
+        if (cj > maxc) nw[j] = (cj + maxc - 1) / maxc;
+        mine += nw[j];
+    }
+    mine = wave_sum_u32(mine);
+    if (lane == 0) sm.wsum[wave] = mine;
+    __syncthreads();
+    u32 j0 = 0, total = 0;
+    for (int w = 0; w < NW; w++) {
+        const u32 t = sm.wsum[w];
+        if (w < wave) j0 += t;
+        total += t;
+    }
+    if (tid == 0) a.nwords[chunk] = total;
+#pragma unroll
+    for (int j = 0; j < SPT; j++) {
+        const u32 inc = wave_incl_scan_u32(nw[j]);
+        if (nw[j]) {
+            const u32 s = (u32)tid + (u32)j * BLOCK;
+            u64 k;
+            if constexpr (TAG32) k = ((u64)sm.keys[s] << a.shift) | low; else k = sm.keys[s];
+            k <<= a.pack;
+            u32 c = sm.cnt[s];
+            u64 pos = gbase + j0 + inc - nw[j];
+            for (u32 q = nw[j]; q > 1; q--) { a.out[pos++] = k | (u64)maxc; c -= maxc; }
+            a.out[pos] = k | (u64)c;
+        }
+        j0 += (u32)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+}
+
+// the words of the blocks, moved together: workgroup (v) copies block v's words from its own place to dst[prefix[v] ..)
+__global__ __launch_bounds__(256) void dedupe_pack_kernel(const u64* __restrict__ in, const u64* __restrict__ cuts, const u64* __restrict__ incl,
+                                                          const u64* __restrict__ nwords, u32 chunks, u64* __restrict__ out) {
+    for (u32 v = blockIdx.x; v < chunks; v += gridDim.x) {
+        const u64 cnt = nwords[v];
+        const u64 dst0 = incl[v] - cnt;
+        const u64* src = in + cuts[v];
+        for (u64 i = threadIdx.x; i < cnt; i += blockDim.x) out[dst0 + i] = src[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // The same pass as a persistent, two-stage pipeline (array source, keys only).
 //
 // Measured on the one-tile-per-workgroup kernel: a tile spends a third of its life in the look-back,
@@ -1618,6 +1836,55 @@ int sort_rbits(zk_ctx* c) {
 int sort_first_bits(zk_ctx* c, int key_bits, int lo_bit) {
     if (lo_bit >= key_bits) return 0;
     return make_plan(key_bits - lo_bit, sort_rbits(c), lo_bit).bits[0];
+}
+
+// keys[0..n) ordered by their low `shift` bits -> out[0..*n_out): one word (key << pack | count) per DISTINCT key, still ordered
+// by the low `shift` bits (dedupe_kernel); a count beyond `pack` bits is spread over several words.  `keys` is consumed: the
+// words are first written block by block into `work` (at least as many words as keys) and then moved together into `keys`
+// (*result = keys).  *flags: bit 0 = some table filled up: the words are not to be used.  max_chunks > 0: only the leading
+// blocks are counted, nothing is moved (the sample; only *n_out and *n_in mean anything).
+int dedupe_pass(zk_ctx* c, u64* keys, uint64_t n, int key_bits, int shift, int pack, u64* work, uint64_t cap, u64** result,
+                uint64_t* n_out, uint32_t* flags, uint64_t* n_in, uint64_t max_chunks) {
+    *n_out = 0; *flags = 0; *result = work;
+    if (n_in) *n_in = n;
+    if (n == 0) return ZK_OK;
+    if (shift < 1 || shift > 24 || pack < 10 || pack > 31) return fail(c, ZK_EINTERNAL, "dedupe_pass: shift %d, pack %d", shift, pack);
+    if (cap < n) return fail(c, ZK_ENOSPC, "dedupe_pass: work buffer of %llu words for %llu keys", (unsigned long long)cap, (unsigned long long)n);
+    DedupeArgs a = {};
+    uint64_t chunks = 1ull << shift;          // one workgroup per block
+    const bool sample = max_chunks > 0;          // counted only, never moved: the keys stay as they are
+    if (sample && chunks > max_chunks) chunks = max_chunks;
+    u64 *cuts, *nwords, *incl;
+    ZK_TRY(arena_alloc(c, sizeof(u64) * (chunks + 1), (void**)&cuts));
+    ZK_TRY(arena_alloc(c, sizeof(u64) * chunks, (void**)&nwords));
+    ZK_TRY(arena_alloc(c, sizeof(u64) * chunks, (void**)&incl));
+    hipLaunchKernelGGL(dedupe_cuts_kernel, dim3((u32)div_up(chunks + 1, 256)), dim3(256), 0, c->stream, keys, (u64)n, shift, (u32)chunks, cuts);
+    a.kin = keys; a.n = n; a.cuts = cuts; a.out = work; a.nwords = nwords; a.shift = shift; a.pack = pack;
+    a.chunks = (u32)chunks;
+    a.flags = (u32*)(c->d_scalars + 27);
+    ZK_HIP(c, hipMemsetAsync(c->d_scalars + 27, 0, sizeof(u64), c->stream));
+    prof_begin(c, ZK_PROF_RLE, 8 * n);
+    // 32-bit entries when the bits above `shift` fit
+    if (key_bits - shift <= 32) hipLaunchKernelGGL(dedupe_kernel<true>, dim3((u32)chunks), dim3(1024), 0, c->stream, a);
+    else hipLaunchKernelGGL(dedupe_kernel<false>, dim3((u32)chunks), dim3(1024), 0, c->stream, a);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(incl, nwords, sizeof(u64) * chunks, hipMemcpyDeviceToDevice, c->stream));
+    ZK_TRY(scan64_inclusive(c, incl, chunks));
+    // the keys are consumed: the words are moved together into their buffer (sample: nothing is moved, only counted)
+    if (!sample) {
+        hipLaunchKernelGGL(dedupe_pack_kernel, dim3((u32)c->num_cus * 8), dim3(256), 0, c->stream, work, cuts, incl, nwords, (u32)chunks, keys);
+        *result = keys;
+    }
+    prof_end(c);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, incl + chunks - 1, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 27, c->d_scalars + 27, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 28, cuts + chunks, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_TRY(check_device_error(c));
+    *n_out = c->h_scalars[9];
+    *flags = (uint32_t)c->h_scalars[27];
+    if (n_in) *n_in = c->h_scalars[28];          // keys covered by the blocks that were counted
+    return ZK_OK;
 }
 
 // keys[0..n) ordered by their low `shift` bits -> out[0..*n_out): one word (key << pack | run length) per run of equal keys
