@@ -935,12 +935,16 @@ __global__ __launch_bounds__(512, 4) void collapse_kernel(CollapseArgs a) {
 // strand), so the block sizes spread from ~0 to 2 x the mean with the last bases; one 1024-thread workgroup per CU.
 template <bool TAG32>
 struct DedupeSmem {
-    static constexpr int BLOCK = 1024, ITEMS = 8, TILE = BLOCK * ITEMS, NW = BLOCK / 64, SLOTS = TAG32 ? 16384 : 12288, SPT = SLOTS / BLOCK,
+    static constexpr int BLOCK = 1024, ITEMS = 8, TILE = BLOCK * ITEMS, NW = BLOCK / 64, SLOTS = TAG32 ? 12288 : 6144, SPT = SLOTS / BLOCK,
                          PROBES = 128;
+    // a wave's side list: what one tile can add at worst (64 * ITEMS) on top of what is left standing after a tile (SIDE_KEEP)
+    static constexpr int SIDE_KEEP = 128, SIDE = SIDE_KEEP + 64 * ITEMS;
     typedef typename std::conditional<TAG32, u32, u64>::type E;
     E keys[SLOTS];
     u32 cnt[SLOTS];
+    E side[NW][SIDE];
     u32 wsum[NW];
+    u32 ticket;
 };
 
 struct DedupeArgs {
@@ -952,6 +956,7 @@ struct DedupeArgs {
     int shift;          // b: the keys are ordered by their low b bits
     int pack;
     u32* flags;         // |= 1: a table filled up
+    u32* counter;       // the next block to take
     u32 chunks;
 };
 
@@ -970,17 +975,15 @@ __global__ void dedupe_cuts_kernel(const u64* __restrict__ k, u64 n, int shift, 
 }
 
 template <bool TAG32>
-__global__ __launch_bounds__(1024, 4) void dedupe_kernel(DedupeArgs a) {
+__device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG32>& sm, const u32 chunk) {
     using S = DedupeSmem<TAG32>;
     using E = typename S::E;
     constexpr int BLOCK = S::BLOCK, ITEMS = S::ITEMS, TILE = S::TILE, NW = S::NW, SLOTS = S::SLOTS, SPT = S::SPT;
     constexpr E EMPTY = (E)~(E)0;            // no entry: a k-mer leaves `pack` >= 10 high bits zero (TAG32: see insert)
-    __shared__ S sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // No order between the workgroups: a block's words go to the block's own place in the output (its input offset) and
+    // No order between the blocks: a block's words go to the block's own place in the output (its input offset) and
     // are moved together afterwards -- a chain of output offsets would make the small blocks wait for the big ones before them
     // (the sizes spread 8 : 1), with one workgroup per CU that is idle silicon.
-    const u32 chunk = blockIdx.x;
     const u64 lo = a.cuts[chunk], hi = a.cuts[chunk + 1];
     const u32 maxc = (1u << a.pack) - 1u;
     if (hi <= lo) {
@@ -991,29 +994,56 @@ __global__ __launch_bounds__(1024, 4) void dedupe_kernel(DedupeArgs a) {
     for (int q = tid; q < SLOTS / 4; q += BLOCK) reinterpret_cast<uint4*>(sm.cnt)[q] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     u32 bad = 0;
-    // One key after the other, each in the tightest loop there is: everything fancier (several keys probing at once,
-    // store-and-verify rounds instead of the compare-and-swap) cost more instructions than it hid latency -- the kernel is bound
-    // by its instruction count (188 per key in the batched form, 110 in this one before the tags and the whole-tile path).
-    auto insert = [&](u64 k) {
-        E e;
+    // The kernel is bound by its instruction count (188 per key with several keys probing at once, 88 with one tight probing
+    // loop per key -- a loop runs as long as the unluckiest of its 64 lanes).  So the common case has NO loop: one
+    // compare-and-swap at the key's home entry; a key that finds another key there goes to the wave's side list (its place
+    // from a ballot, no atomic), and the lists -- about a tenth of the distinct keys with all their copies -- are inserted with
+    // the probing loop afterwards, by full wavefronts.  A list that fills up is worked off on the spot.
+    constexpr u32 HS = TAG32 ? SLOTS - 1 : SLOTS;          // TAG32: see `home`
+    u32 nside = 0;          // entries in this wave's side list (the same in every lane)
+    auto entry_of = [&](u64 k) -> E { if constexpr (TAG32) return (E)(u32)(k >> a.shift); else return (E)k; };
+    auto home = [&](E e, u64 k) -> u32 {
         u32 x;
-        if constexpr (TAG32) { e = (u32)(k >> a.shift); x = e * 0x9E3779B1u; }
-        else { e = k; x = ((u32)(k >> a.shift) ^ ((u32)k * 0x85EBCA6Bu)) * 0x9E3779B1u; }
-        // TAG32: the tag may use all 32 bits, so the all-ones tag (= the empty marker) has the last entry to itself: it is never
-        // probed, its key word stays all ones, and only its count says whether it is there
-        constexpr u32 HS = TAG32 ? SLOTS - 1 : SLOTS;
-        u32 h = (u32)(((u64)x * HS) >> 32);
-        int p = 0;
-        if (TAG32 && e == EMPTY) h = HS;
-        else
-        for (; p < S::PROBES; p++) {
-            E old;
-            if constexpr (TAG32) old = atomicCAS(&sm.keys[h], EMPTY, e);
-            else old = atomicCAS(reinterpret_cast<unsigned long long*>(&sm.keys[h]), (unsigned long long)EMPTY, (unsigned long long)e);
-            if (old == EMPTY || old == e) break;
-            h = h + 1 == HS ? 0u : h + 1;
+        if constexpr (TAG32) x = (u32)e * 0x9E3779B1u; else x = ((u32)(k >> a.shift) ^ ((u32)k * 0x85EBCA6Bu)) * 0x9E3779B1u;
+        // TAG32: the tag may use all 32 bits, so the all-ones tag (= the empty marker) has the last entry to itself: never
+        // probed, its key word stays all ones, only its count says whether it is there
+        if (TAG32 && e == EMPTY) return HS;
+        return (u32)(((u64)x * HS) >> 32);
+    };
+    auto cas = [&](u32 h, E e) -> E {
+        if constexpr (TAG32) return atomicCAS(&sm.keys[h], EMPTY, e);
+        else return (E)atomicCAS(reinterpret_cast<unsigned long long*>(&sm.keys[h]), (unsigned long long)EMPTY, (unsigned long long)e);
+    };
+    auto drain = [&]() {          // the wave's side list into the table by linear probing, 64 entries at a time
+        for (u32 i = (u32)lane; i < nside; i += 64) {
+            const E e = sm.side[wave][i];
+            u32 x;
+            if constexpr (TAG32) x = (u32)e * 0x9E3779B1u; else x = ((u32)((u64)e >> a.shift) ^ ((u32)e * 0x85EBCA6Bu)) * 0x9E3779B1u;
+            u32 h = (u32)(((u64)x * HS) >> 32) + 1;          // its home entry is taken: that is why it is here
+            h = h == HS ? 0u : h;
+            int p = 0;
+            for (; p < S::PROBES; p++) {
+                const E old = cas(h, e);
+                if (old == EMPTY || old == e) break;
+                h = h + 1 == HS ? 0u : h + 1;
+            }
+            if (p < S::PROBES) atomicAdd(&sm.cnt[h], 1u); else bad = 1;
         }
-        if (p < S::PROBES) atomicAdd(&sm.cnt[h], 1u); else bad = 1;
+        nside = 0;
+    };
+    // No branch in the common case: the count is added as 1 or 0 (adding 0 to another key's entry harms nobody), and the all-ones
+    // tag needs no special case (at its own entry the swap of "empty" for "empty" succeeds and leaves the word as it is).
+    auto insert = [&](u64 k, bool valid) {
+        const E e = entry_of(k);
+        const u32 h = home(e, k);
+        const E old = valid ? cas(h, e) : e;
+        const bool ok = old == EMPTY || old == e;
+        atomicAdd(&sm.cnt[h], (ok && valid) ? 1u : 0u);
+        const u64 m = __ballot(!ok);
+        if (m) {
+            if (!ok) sm.side[wave][nside + popc_below(m)] = e;
+            nside += (u32)__popcll(m);
+        }
     };
     u64 key[ITEMS], nk[ITEMS];
     // whole tiles: one address, constant offsets; the cut last tile: per-key bounds
@@ -1035,14 +1065,14 @@ __global__ __launch_bounds__(1024, 4) void dedupe_kernel(DedupeArgs a) {
         if (base + TILE < hi) load(base + TILE, nk);
         if (base + TILE <= hi) {
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++) insert(key[i]);
+            for (int i = 0; i < ITEMS; i++) insert(key[i], true);
         } else {
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++)
-                if (key[i] != ~0ull) insert(key[i]);
+            for (int i = 0; i < ITEMS; i++) insert(key[i], key[i] != ~0ull);
         }
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) key[i] = nk[i];
+        if (nside > (u32)S::SIDE_KEEP || base + TILE >= hi) drain();
     }
     if (bad) atomicOr(a.flags, 1u);
     __syncthreads();
@@ -1118,6 +1148,21 @@ __global__ __launch_bounds__(1024, 4) void dedupe_kernel(DedupeArgs a) {
             a.out[pos] = k | (u64)c;
         }
         j0 += (u32)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+}
+
+// Persistent: one workgroup per CU (the table takes most of its LDS) draws the blocks from a counter -- in order, not strided:
+// the sizes go with the last base, a stride of the grid would give one workgroup all the big ones.
+template <bool TAG32>
+__global__ __launch_bounds__(1024, 4) void dedupe_kernel(DedupeArgs a) {
+    __shared__ DedupeSmem<TAG32> sm;
+    for (;;) {
+        if (threadIdx.x == 0) sm.ticket = atomicAdd(a.counter, 1u);
+        __syncthreads();
+        const u32 chunk = (u32)__builtin_amdgcn_readfirstlane((int)sm.ticket);
+        if (chunk >= a.chunks) break;
+        dedupe_block<TAG32>(a, sm, chunk);
+        __syncthreads();          // the table and the ticket word are free again
     }
 }
 
@@ -1862,11 +1907,13 @@ int dedupe_pass(zk_ctx* c, u64* keys, uint64_t n, int key_bits, int shift, int p
     a.kin = keys; a.n = n; a.cuts = cuts; a.out = work; a.nwords = nwords; a.shift = shift; a.pack = pack;
     a.chunks = (u32)chunks;
     a.flags = (u32*)(c->d_scalars + 27);
-    ZK_HIP(c, hipMemsetAsync(c->d_scalars + 27, 0, sizeof(u64), c->stream));
+    a.counter = (u32*)(c->d_scalars + 29);
+    ZK_HIP(c, hipMemsetAsync(c->d_scalars + 27, 0, 3 * sizeof(u64), c->stream));
     prof_begin(c, ZK_PROF_RLE, 8 * n);
     // 32-bit entries when the bits above `shift` fit
-    if (key_bits - shift <= 32) hipLaunchKernelGGL(dedupe_kernel<true>, dim3((u32)chunks), dim3(1024), 0, c->stream, a);
-    else hipLaunchKernelGGL(dedupe_kernel<false>, dim3((u32)chunks), dim3(1024), 0, c->stream, a);
+    const u32 grid = chunks < (uint64_t)c->num_cus ? (u32)chunks : (u32)c->num_cus;
+    if (key_bits - shift <= 32) hipLaunchKernelGGL(dedupe_kernel<true>, dim3(grid), dim3(1024), 0, c->stream, a);
+    else hipLaunchKernelGGL(dedupe_kernel<false>, dim3(grid), dim3(1024), 0, c->stream, a);
     ZK_HIP(c, hipGetLastError());
     ZK_HIP(c, hipMemcpyAsync(incl, nwords, sizeof(u64) * chunks, hipMemcpyDeviceToDevice, c->stream));
     ZK_TRY(scan64_inclusive(c, incl, chunks));
