@@ -121,8 +121,17 @@ int sort_pairs_mirrored(zk_ctx* c, const u64* src_k, const u32* src_v, u64* keys
 struct StreamSrc { const u8* stream; uint64_t n_bytes; int K; int mode; int lo_bit; int hi_bit = 0; };   // mode: ZK_KEYS_*; sort bits [lo_bit, hi_bit) (hi_bit 0 = 2K)
 int sort_rbits(zk_ctx* c);
 int sort_first_bits(zk_ctx* c, int key_bits, int lo_bit);
-int dedupe_pass(zk_ctx* c, u64* keys, uint64_t n, int key_bits, int shift, int pack, u64* work, uint64_t cap, u64** result,
-                uint64_t* n_out, uint32_t* flags, uint64_t* n_in = nullptr, uint64_t max_chunks = 0);
+struct DedupeResult {
+    uint64_t n_out = 0;          // distinct keys
+    uint32_t flags = 0;          // bit 0: a table filled up (unusable), bit 1: counts beyond the packed field exist (patched by dedupe_finish)
+    uint32_t n_big = 0;
+    u64 *cuts = nullptr, *nwords = nullptr, *incl = nullptr, *big = nullptr, *work = nullptr;
+    uint32_t chunks = 0;
+    int pack = 0;
+};
+int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int pack, u64* work, uint64_t cap, DedupeResult* r,
+                uint64_t* n_in = nullptr, uint64_t max_chunks = 0);
+int dedupe_finish(zk_ctx* c, const DedupeResult& r, u64* out_k, u32* out_c);
 int collapse_pass(zk_ctx* c, const u64* keys, uint64_t n, int shift, int bits, int pack, u64* out, uint64_t cap, uint64_t* n_out,
                   uint64_t max_tiles = 0);
 int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,

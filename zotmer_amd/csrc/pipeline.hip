@@ -230,9 +230,10 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
         if (b + rb / 2 < 2 * K) collapse_bit = b;
         if (collapse_bit >= 2 * rb && (c->early_collapse == 1 || c->early_collapse == 3) && c->packed_pairs && pack_bits_for(K)) fused_bit = collapse_bit - rb;
     }
-    // One pass earlier still while the blocks of keys that share their sorted low bits are small enough for an LDS hash table
-    // (dedupe_kernel: at most 32 K keys per block by the stream's length, at least 2 K so that the copies of a k-mer are spread
-    // over many wavefronts): config 2 is counted after TWO passes.
+    // Better still while the blocks of keys that share b sorted bits are small enough for an LDS hash table (dedupe_kernel: at
+    // most 32 K keys per block by the stream's length, at least 2 K so that the copies of a k-mer are spread over many
+    // wavefronts): the passes then sort the TOP b bits, the table counts each block and leaves it sorted by the bits below --
+    // config 2 is done after TWO passes.
     int dedupe_bit = 0;
     if (fused_bit && c->early_collapse == 1) {
         const int lg = ilog2_ceil(n_bytes);
@@ -240,7 +241,8 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
         const int b = rb * passes;
         if (b < fused_bit + rb && b + rb / 2 < 2 * K && b <= 24 && (n_bytes >> b) >= 2048) dedupe_bit = b;
     }
-    src.hi_bit = dedupe_bit ? dedupe_bit : (fused_bit ? fused_bit : collapse_bit);
+    if (dedupe_bit) { src.lo_bit = 2 * K - dedupe_bit; src.hi_bit = 0; }
+    else src.hi_bit = fused_bit ? fused_bit : collapse_bit;
     uint64_t n = 0;
     u64* sorted = nullptr;
     ZK_TRY(sort_stream(c, src, buf_a, buf_b, cap_keys, &n, st->acgt, &sorted));
@@ -259,32 +261,31 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     bool have_max = false;
     if (dedupe_bit && n) {
         const int pk = pack_bits_for(K);
-        uint64_t us = 0, u1 = 0, n_in = 0;
-        uint32_t fl = 0;
+        DedupeResult r;
+        uint64_t n_in = 0;
         bool done = false;
         // the sample: the leading blocks, about a million keys
         const uint64_t nblocks = 1ull << dedupe_bit, per = n / nblocks + 1;
-        u64* words = nullptr;
-        ZK_TRY(dedupe_pass(c, sorted, n, 2 * K, dedupe_bit, pk, other, cap_keys, &words, &us, &fl, &n_in, (1u << 20) / per + 1));
-        if (!fl && (double)us <= 0.6 * (double)n_in) {
-            ZK_TRY(dedupe_pass(c, sorted, n, 2 * K, dedupe_bit, pk, other, cap_keys, &words, &u1, &fl));
-            if (!fl) {
-                u64* res = nullptr;
-                ZK_TRY(sort_keys_upper(c, words, other, u1, 2 * K + pk, dedupe_bit + pk, &res));          // words == sorted: the keys are gone
-                const uint64_t a8 = (8 * u1 + 255) & ~255ull, a4 = (4 * u1 + 255) & ~255ull;
+        ZK_TRY(dedupe_pass(c, sorted, n, 2 * K, dedupe_bit, pk, other, cap_keys, &r, &n_in, (1u << 20) / per + 4));
+        if (!(r.flags & 1) && (double)r.n_out <= 0.6 * (double)n_in) {
+            ZK_TRY(dedupe_pass(c, sorted, n, 2 * K, dedupe_bit, pk, other, cap_keys, &r));
+            if (!(r.flags & 1)) {
+                uc = r.n_out;
+                const uint64_t a8 = (8 * uc + 255) & ~255ull, a4 = (4 * uc + 255) & ~255ull;
                 char* aux;
                 ZK_TRY(aux_require(c, a8 + a4, &aux));
-                ZK_TRY(reduce_by_key(c, res, nullptr, u1, (u64*)aux, (u32*)(aux + a8), u1, &uc, pk, &max_count));
+                ZK_TRY(dedupe_finish(c, r, (u64*)aux, (u32*)(aux + a8)));
                 sorted = (u64*)aux; cnt = (u32*)(aux + a8);
                 in_aux = true;
-                have_max = true;
+                if (!(r.flags & 2)) { max_count = (1ull << pk) - 1; have_max = true; }          // every count fits the field
                 done = true;
             }
         }
         if (!done) {
-            // little duplication, or a table filled up: the keys (untouched: the words went to the other buffer) finish the sort
+            // little duplication, or a table filled up: the keys (untouched: the words went to the other buffer) are sorted the
+            // long way, all their bits -- the two passes over the top bits were for nothing
             u64* res = nullptr;
-            ZK_TRY(sort_keys_upper(c, sorted, other, n, 2 * K, dedupe_bit, &res, ZK_PROF_PASS_KEYS));
+            ZK_TRY(sort_keys(c, sorted, other, n, 2 * K, &res));
             sorted = res;
             other = (sorted == buf_a) ? buf_b : buf_a;
             cnt = (u32*)other;

@@ -915,61 +915,64 @@ __global__ __launch_bounds__(512, 4) void collapse_kernel(CollapseArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Block dedupe (zk_kmerize, canonical keys; see pipeline.hip::kmerize_full) -- the collapse one pass earlier still.
+// Block dedupe (zk_kmerize, canonical keys; see pipeline.hip::kmerize_full): counting AND finishing the sort in LDS.
 //
-// With the low b bits sorted, ALL copies of a k-mer lie in the block of keys that share those b bits (they share every bit).
-// While such a block is small -- n / 2^b keys; 23.7 K after two passes on config 2 -- it is counted in an LDS hash table:
-// one workgroup per block (2^b of them; boundaries by binary search) claims an entry per distinct key with a 64-bit
-// compare-and-swap, counts copies with an add, and writes one word (key << pack | count) per entry, blocks one after the
-// other.  Every k-mer is then counted completely -- no run is ever cut -- and the words are still ordered by their low b
-// bits (inside a block the order is the table's, which does not matter: they all share those bits), so the LSD passes
-// over the words continue at bit b.  Unlike the tile-local variant (collapse_kernel: copies within a few dozen slots of
-// each other, i.e. in the same 64 lanes, where a table suffers same-address conflicts on every instruction), the copies are
-// spread over the whole block here and the atomics run conflict-free.
-// A count beyond the packed field goes out as several words with the same key (reduce_by_key adds up equal keys after the
-// sort anyway).  A table that fills up (a chunk with more than ~5 K distinct keys: little duplication) raises a flag and the
-// caller takes another path -- the result never depends on the table.
+// After LSD passes over the TOP b bits of the keys, the keys that share those bits form a block -- and all copies of a k-mer
+// lie in one block (they share every bit).  While a block is small (n / 2^b keys; 23.7 K after two passes on config 2) one
+// workgroup counts it in an LDS hash table: a compare-and-swap claims an entry for a key's remaining bits (its tag), an add
+// counts the copy.  The block's entries (~3 K distinct tags) are then sorted right there: a counting sort on the tag's top byte
+// (LDS counters), and inside each byte's group of a dozen entries the place is the number of smaller tags.  The block's
+// distinct k-mers therefore leave the kernel SORTED, and the blocks are in the order of their top bits: the counted list
+// needs no further sort pass at all.
+// The copies of a k-mer are spread over the whole block (unlike in the tile-local table variant that was measured for
+// collapse_kernel, where they sit in the same 64 lanes), so the atomics rarely collide.
+// Words (key << pack | count) go to the block's own place in `out` (its input offset: never more words than keys);
+// dedupe_unpack_kernel moves them together and splits them into keys and counts.  A count beyond the field leaves the field 0
+// and goes to a side list that patches the count afterwards.  A table that fills up (more than ~6 K distinct keys in a block:
+// little duplication) raises a flag and the caller sorts the keys the long way -- the result never depends on the table.
 // ---------------------------------------------------------------------------------------
-// TAG32: the bits of a key above `shift` fit 32 bits (the bits below are the block's number): entries of 4 + 4 bytes, 16 K of them.
-// 12 K / 16 K entries: the blocks are not of one size -- a canonical k-mer more often ends in A than in T (it is the smaller
-// strand), so the block sizes spread from ~0 to 2 x the mean with the last bases; one 1024-thread workgroup per CU.
+// TAG32: a tag fits 32 bits: entries of 4 + 4 bytes.  The blocks are not of one size -- a canonical k-mer more often starts with
+// A than with T (it is the smaller strand), so the sizes spread from ~0 to 2 x the mean with the first bases; the table is sized
+// for the big ones: one 1024-thread workgroup per CU.
 template <bool TAG32>
 struct DedupeSmem {
-    static constexpr int BLOCK = 1024, ITEMS = 8, TILE = BLOCK * ITEMS, NW = BLOCK / 64, SLOTS = TAG32 ? 12288 : 6144, SPT = SLOTS / BLOCK,
-                         PROBES = 128;
+    static constexpr int BLOCK = 1024, ITEMS = 8, TILE = BLOCK * ITEMS, NW = BLOCK / 64, ALL = TAG32 ? 12288 : 6144, SPT = ALL / BLOCK, NB = 256;
     // a wave's side list: what one tile can add at worst (64 * ITEMS) on top of what is left standing after a tile (SIDE_KEEP)
     static constexpr int SIDE_KEEP = 128, SIDE = SIDE_KEEP + 64 * ITEMS;
     typedef typename std::conditional<TAG32, u32, u64>::type E;
-    E keys[SLOTS];
-    u32 cnt[SLOTS];
+    E keys[ALL];             // tags (after the count: the entries again, grouped by their top byte)
+    u32 cnt[ALL];
     E side[NW][SIDE];
-    u32 wsum[NW];
+    u32 bc[NB];              // entries per top byte of the tag
+    u32 bbase[NB + 1];       // ... before it
+    u32 bfill[NB];
     u32 ticket;
 };
 
 struct DedupeArgs {
     const u64* kin;
     u64 n;
-    const u64* cuts;    // [chunks + 1]: chunk v = the block of keys whose low `shift` bits are v
-    u64* out;           // block v writes its words from out + cuts[v] on (never more words than keys); dedupe_pack_kernel closes the gaps
+    const u64* cuts;    // [chunks + 1]: chunk v = the block of keys whose top bits are v
+    u64* out;           // block v writes its words from out + cuts[v] on; dedupe_unpack_kernel closes the gaps
     u64* nwords;        // [chunks] words of block v
-    int shift;          // b: the keys are ordered by their low b bits
+    int tag_bits;       // key bits below the block bits
     int pack;
-    u32* flags;         // |= 1: a table filled up
+    u32* flags;         // |= 1: a table filled up, |= 2: some count went to the side list
     u32* counter;       // the next block to take
+    u64* big;           // (key, count) pairs whose count does not fit `pack` bits
+    u32* n_big;
+    u32 big_cap;
     u32 chunks;
 };
 
-// cuts[v] = first index whose low `shift` bits are >= v, v = 0 .. blocks (blocks = 2^shift unless only the leading ones are wanted)
-__global__ void dedupe_cuts_kernel(const u64* __restrict__ k, u64 n, int shift, u32 blocks, u64* __restrict__ cuts) {
+// cuts[v] = first index whose key >> tag_bits is >= v, v = 0 .. blocks
+__global__ void dedupe_cuts_kernel(const u64* __restrict__ k, u64 n, int tag_bits, u32 blocks, u64* __restrict__ cuts) {
     const u32 v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v > blocks) return;
-    const u64 mask = (1ull << shift) - 1;
     u64 lo = 0, hi = n;
-    if (((u64)v >> shift) != 0) lo = n;          // v = 2^shift: the end
     while (lo < hi) {
         const u64 mid = (lo + hi) >> 1;
-        if ((k[mid] & mask) < (u64)v) lo = mid + 1; else hi = mid;
+        if ((k[mid] >> tag_bits) < (u64)v) lo = mid + 1; else hi = mid;
     }
     cuts[v] = lo;
 }
@@ -978,35 +981,35 @@ template <bool TAG32>
 __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG32>& sm, const u32 chunk) {
     using S = DedupeSmem<TAG32>;
     using E = typename S::E;
-    constexpr int BLOCK = S::BLOCK, ITEMS = S::ITEMS, TILE = S::TILE, NW = S::NW, SLOTS = S::SLOTS, SPT = S::SPT;
-    constexpr E EMPTY = (E)~(E)0;            // no entry: a k-mer leaves `pack` >= 10 high bits zero (TAG32: see insert)
+    constexpr int BLOCK = S::BLOCK, ITEMS = S::ITEMS, TILE = S::TILE, ALL = S::ALL, SPT = S::SPT, NB = S::NB;
+    constexpr E EMPTY = (E)~(E)0;            // no entry.  A 64-bit tag never has all its bits set; a 32-bit one may: see `home`
+    constexpr u32 HS = TAG32 ? ALL - 1 : ALL;          // ... then the last entry belongs to the all-ones tag alone
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // No order between the blocks: a block's words go to the block's own place in the output (its input offset) and
-    // are moved together afterwards -- a chain of output offsets would make the small blocks wait for the big ones before them
-    // (the sizes spread 8 : 1), with one workgroup per CU that is idle silicon.
     const u64 lo = a.cuts[chunk], hi = a.cuts[chunk + 1];
     const u32 maxc = (1u << a.pack) - 1u;
     if (hi <= lo) {
         if (tid == 0) a.nwords[chunk] = 0;
         return;
     }
-    for (int q = tid; q < SLOTS * (int)sizeof(E) / 16; q += BLOCK) reinterpret_cast<uint4*>(sm.keys)[q] = make_uint4(~0u, ~0u, ~0u, ~0u);
-    for (int q = tid; q < SLOTS / 4; q += BLOCK) reinterpret_cast<uint4*>(sm.cnt)[q] = make_uint4(0, 0, 0, 0);
+    for (int q = tid; q < ALL * (int)sizeof(E) / 16; q += BLOCK) reinterpret_cast<uint4*>(sm.keys)[q] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    for (int q = tid; q < ALL / 4; q += BLOCK) reinterpret_cast<uint4*>(sm.cnt)[q] = make_uint4(0, 0, 0, 0);
+    if (tid < NB) { sm.bc[tid] = 0; sm.bfill[tid] = 0; }
     __syncthreads();
     u32 bad = 0;
     // The kernel is bound by its instruction count (188 per key with several keys probing at once, 88 with one tight probing
-    // loop per key -- a loop runs as long as the unluckiest of its 64 lanes).  So the common case has NO loop: one
-    // compare-and-swap at the key's home entry; a key that finds another key there goes to the wave's side list (its place
-    // from a ballot, no atomic), and the lists -- about a tenth of the distinct keys with all their copies -- are inserted with
-    // the probing loop afterwards, by full wavefronts.  A list that fills up is worked off on the spot.
-    constexpr u32 HS = TAG32 ? SLOTS - 1 : SLOTS;          // TAG32: see `home`
+    // loop per key -- a loop runs as long as the unluckiest of its 64 lanes).  So the common case has NO loop and no branch:
+    // one compare-and-swap at the key's home entry, the count added as 1 or 0 (adding 0 to another key's entry harms nobody);
+    // a key that finds another key at home goes to the wave's side list (its place from a ballot, no atomic), and the lists --
+    // about a tenth of the distinct keys with all their copies -- are inserted by linear probing afterwards, full wavefronts.
+    // (An order-preserving "hash" -- the tag scaled to the table -- would leave the table sorted, but the error variants of a
+    // k-mer differ from it in a few low bits and all want the same entry: 45 ms instead of 17.)
+    const u64 tmask = (1ull << a.tag_bits) - 1;
     u32 nside = 0;          // entries in this wave's side list (the same in every lane)
-    auto entry_of = [&](u64 k) -> E { if constexpr (TAG32) return (E)(u32)(k >> a.shift); else return (E)k; };
-    auto home = [&](E e, u64 k) -> u32 {
+    auto home = [&](E e) -> u32 {
+        // the all-ones 32-bit tag (= the empty marker) has the last entry to itself: there the swap of "empty" for "empty"
+        // succeeds and leaves the word as it is; no other key is ever sent there
         u32 x;
-        if constexpr (TAG32) x = (u32)e * 0x9E3779B1u; else x = ((u32)(k >> a.shift) ^ ((u32)k * 0x85EBCA6Bu)) * 0x9E3779B1u;
-        // TAG32: the tag may use all 32 bits, so the all-ones tag (= the empty marker) has the last entry to itself: never
-        // probed, its key word stays all ones, only its count says whether it is there
+        if constexpr (TAG32) x = (u32)e * 0x9E3779B1u; else x = ((u32)((u64)e >> 24) ^ ((u32)e * 0x85EBCA6Bu)) * 0x9E3779B1u;
         if (TAG32 && e == EMPTY) return HS;
         return (u32)(((u64)x * HS) >> 32);
     };
@@ -1017,25 +1020,21 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
     auto drain = [&]() {          // the wave's side list into the table by linear probing, 64 entries at a time
         for (u32 i = (u32)lane; i < nside; i += 64) {
             const E e = sm.side[wave][i];
-            u32 x;
-            if constexpr (TAG32) x = (u32)e * 0x9E3779B1u; else x = ((u32)((u64)e >> a.shift) ^ ((u32)e * 0x85EBCA6Bu)) * 0x9E3779B1u;
-            u32 h = (u32)(((u64)x * HS) >> 32) + 1;          // its home entry is taken: that is why it is here
+            u32 h = home(e) + 1;          // its home entry is taken: that is why it is here
             h = h == HS ? 0u : h;
             int p = 0;
-            for (; p < S::PROBES; p++) {
+            for (; p < ALL; p++) {
                 const E old = cas(h, e);
                 if (old == EMPTY || old == e) break;
                 h = h + 1 == HS ? 0u : h + 1;
             }
-            if (p < S::PROBES) atomicAdd(&sm.cnt[h], 1u); else bad = 1;
+            if (p < ALL) atomicAdd(&sm.cnt[h], 1u); else bad = 1;
         }
         nside = 0;
     };
-    // No branch in the common case: the count is added as 1 or 0 (adding 0 to another key's entry harms nobody), and the all-ones
-    // tag needs no special case (at its own entry the swap of "empty" for "empty" succeeds and leaves the word as it is).
     auto insert = [&](u64 k, bool valid) {
-        const E e = entry_of(k);
-        const u32 h = home(e, k);
+        const E e = (E)(k & tmask);
+        const u32 h = home(e);
         const E old = valid ? cas(h, e) : e;
         const bool ok = old == EMPTY || old == e;
         atomicAdd(&sm.cnt[h], (ok && valid) ? 1u : 0u);
@@ -1074,85 +1073,63 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
         for (int i = 0; i < ITEMS; i++) key[i] = nk[i];
         if (nside > (u32)S::SIDE_KEEP || base + TILE >= hi) drain();
     }
-    if (bad) atomicOr(a.flags, 1u);
+    if (bad) { atomicOr(a.flags, 1u); a.flags[1] = chunk; }          // (the second word: one of the blocks it happened in, for diagnosis)
     __syncthreads();
-    // ---- words per entry: thread t owns the entries t, t + BLOCK, ...; one word unless the count exceeds the field ------
-    u32 occ = 0, big = 0;
+    // ---- the block's entries, sorted: a counting sort on the tag's top byte, then ranks inside each byte's group ---------
+    // thread t takes the entries t, t + BLOCK, ... into registers; the table's memory then takes them back grouped
+    E et[SPT];
+    u32 ec[SPT];
+    const int bsh = a.tag_bits > 8 ? a.tag_bits - 8 : 0;
 #pragma unroll
     for (int j = 0; j < SPT; j++) {
-        const u32 cj = sm.cnt[tid + j * BLOCK];
-        occ |= (cj ? 1u : 0u) << j;
-        big |= cj > maxc ? 1u : 0u;
+        et[j] = sm.keys[tid + j * BLOCK];
+        ec[j] = sm.cnt[tid + j * BLOCK];
+        if (ec[j]) atomicAdd(&sm.bc[(u32)((u64)et[j] >> bsh) & (NB - 1)], 1u);
     }
-    const u64 gbase = lo;
-    const u64 low = (u64)chunk;          // TAG32: the bits of every key of the block below `shift`
-    if (!__syncthreads_or((int)big)) {
-        // the usual case: one word per entry -- ballots and bit counts
-        u32 mine = 0;
-#pragma unroll
-        for (int j = 0; j < SPT; j++) mine += (u32)__popcll(__ballot((occ >> j) & 1u));
-        if (lane == 0) sm.wsum[wave] = mine;
-        __syncthreads();
-        u32 j0 = 0, total = 0;
-        for (int w = 0; w < NW; w++) {
-            const u32 t = sm.wsum[w];
-            if (w < wave) j0 += t;
-            total += t;
-        }
-        if (tid == 0) a.nwords[chunk] = total;
-#pragma unroll
-        for (int j = 0; j < SPT; j++) {
-            const bool on = (occ >> j) & 1u;
-            const u64 m = __ballot(on);
-            if (on) {
-                const u32 s = (u32)tid + (u32)j * BLOCK;
-                u64 k;
-                if constexpr (TAG32) k = ((u64)sm.keys[s] << a.shift) | low; else k = sm.keys[s];
-                a.out[gbase + j0 + popc_below(m)] = (k << a.pack) | (u64)sm.cnt[s];
-            }
-            j0 += (u32)__popcll(m);
-        }
-        return;
-    }
-    // some count is beyond the field: it goes out as several words with the same key (reduce_by_key adds them up again)
-    u32 nw[SPT];
-    u32 mine = 0;
-#pragma unroll
-    for (int j = 0; j < SPT; j++) {
-        const u32 cj = sm.cnt[tid + j * BLOCK];
-        nw[j] = cj ? 1u : 0u;
-        if (cj > maxc) nw[j] = (cj + maxc - 1) / maxc;
-        mine += nw[j];
-    }
-    mine = wave_sum_u32(mine);
-    if (lane == 0) sm.wsum[wave] = mine;
     __syncthreads();
-    u32 j0 = 0, total = 0;
-    for (int w = 0; w < NW; w++) {
-        const u32 t = sm.wsum[w];
-        if (w < wave) j0 += t;
-        total += t;
+    if (wave == 0) {
+        u32 c4[4], sum = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { c4[r] = sm.bc[4 * lane + r]; sum += c4[r]; }
+        const u32 inc = wave_incl_scan_u32(sum);
+        u32 run = inc - sum;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { sm.bbase[4 * lane + r] = run; run += c4[r]; }
+        if (lane == 63) sm.bbase[NB] = inc;
     }
+    __syncthreads();
+    const u32 total = sm.bbase[NB];
     if (tid == 0) a.nwords[chunk] = total;
 #pragma unroll
     for (int j = 0; j < SPT; j++) {
-        const u32 inc = wave_incl_scan_u32(nw[j]);
-        if (nw[j]) {
-            const u32 s = (u32)tid + (u32)j * BLOCK;
-            u64 k;
-            if constexpr (TAG32) k = ((u64)sm.keys[s] << a.shift) | low; else k = sm.keys[s];
-            k <<= a.pack;
-            u32 c = sm.cnt[s];
-            u64 pos = gbase + j0 + inc - nw[j];
-            for (u32 q = nw[j]; q > 1; q--) { a.out[pos++] = k | (u64)maxc; c -= maxc; }
-            a.out[pos] = k | (u64)c;
+        if (ec[j]) {
+            const u32 b = (u32)((u64)et[j] >> bsh) & (NB - 1);
+            const u32 p = sm.bbase[b] + atomicAdd(&sm.bfill[b], 1u);
+            sm.keys[p] = et[j];
+            sm.cnt[p] = ec[j];
         }
-        j0 += (u32)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+    __syncthreads();
+    const u64 hi_part = (u64)chunk << a.tag_bits;          // the bits every key of the block has above its tag
+    for (u32 i = (u32)tid; i < total; i += BLOCK) {
+        const E mine = sm.keys[i];
+        const u32 b = (u32)((u64)mine >> bsh) & (NB - 1);
+        const u32 g0 = sm.bbase[b], g1 = sm.bbase[b + 1];
+        u32 rank = 0;
+        for (u32 q = g0; q < g1; q++) rank += sm.keys[q] < mine ? 1u : 0u;
+        const u32 c = sm.cnt[i];
+        const u64 k = hi_part | (u64)mine;
+        if (c > maxc) {
+            const u32 at = atomicAdd(a.n_big, 1u);
+            if (at < a.big_cap) { a.big[2 * (u64)at] = k; a.big[2 * (u64)at + 1] = c; }
+            atomicOr(a.flags, 2u);
+        }
+        a.out[lo + g0 + rank] = (k << a.pack) | (u64)(c > maxc ? 0u : c);
     }
 }
 
 // Persistent: one workgroup per CU (the table takes most of its LDS) draws the blocks from a counter -- in order, not strided:
-// the sizes go with the last base, a stride of the grid would give one workgroup all the big ones.
+// the sizes go with the first bases, a stride of the grid would give one workgroup all the big ones.
 template <bool TAG32>
 __global__ __launch_bounds__(1024, 4) void dedupe_kernel(DedupeArgs a) {
     __shared__ DedupeSmem<TAG32> sm;
@@ -1166,15 +1143,31 @@ __global__ __launch_bounds__(1024, 4) void dedupe_kernel(DedupeArgs a) {
     }
 }
 
-// the words of the blocks, moved together: workgroup (v) copies block v's words from its own place to dst[prefix[v] ..)
-__global__ __launch_bounds__(256) void dedupe_pack_kernel(const u64* __restrict__ in, const u64* __restrict__ cuts, const u64* __restrict__ incl,
-                                                          const u64* __restrict__ nwords, u32 chunks, u64* __restrict__ out) {
+// the words of the blocks, moved together and taken apart: block v's words -> keys / counts [incl[v] - nwords[v], incl[v])
+__global__ __launch_bounds__(256) void dedupe_unpack_kernel(const u64* __restrict__ in, const u64* __restrict__ cuts, const u64* __restrict__ incl,
+                                                            const u64* __restrict__ nwords, u32 chunks, int pack, u64* __restrict__ out_k,
+                                                            u32* __restrict__ out_c) {
+    const u64 maxc = (1ull << pack) - 1;
     for (u32 v = blockIdx.x; v < chunks; v += gridDim.x) {
         const u64 cnt = nwords[v];
         const u64 dst0 = incl[v] - cnt;
         const u64* src = in + cuts[v];
-        for (u64 i = threadIdx.x; i < cnt; i += blockDim.x) out[dst0 + i] = src[i];
+        for (u64 i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const u64 w = src[i];
+            out_k[dst0 + i] = w >> pack;
+            out_c[dst0 + i] = (u32)(w & maxc);
+        }
     }
+}
+
+// the counts that did not fit a word: found again by key in the sorted list
+__global__ void dedupe_big_kernel(const u64* __restrict__ big, u32 n_big, const u64* __restrict__ k, u64 n, u32* __restrict__ c, u32* err) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_big) return;
+    const u64 key = big[2 * (u64)t], cnt = big[2 * (u64)t + 1];
+    u64 lo = 0, hi = n;
+    while (lo < hi) { const u64 mid = (lo + hi) >> 1; if (k[mid] < key) lo = mid + 1; else hi = mid; }
+    if (lo < n && k[lo] == key) c[lo] = (u32)cnt; else atomicOr(err, ZK_DERR_CAPACITY);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1883,54 +1876,65 @@ int sort_first_bits(zk_ctx* c, int key_bits, int lo_bit) {
     return make_plan(key_bits - lo_bit, sort_rbits(c), lo_bit).bits[0];
 }
 
-// keys[0..n) ordered by their low `shift` bits -> out[0..*n_out): one word (key << pack | count) per DISTINCT key, still ordered
-// by the low `shift` bits (dedupe_kernel); a count beyond `pack` bits is spread over several words.  `keys` is consumed: the
-// words are first written block by block into `work` (at least as many words as keys) and then moved together into `keys`
-// (*result = keys).  *flags: bit 0 = some table filled up: the words are not to be used.  max_chunks > 0: only the leading
-// blocks are counted, nothing is moved (the sample; only *n_out and *n_in mean anything).
-int dedupe_pass(zk_ctx* c, u64* keys, uint64_t n, int key_bits, int shift, int pack, u64* work, uint64_t cap, u64** result,
-                uint64_t* n_out, uint32_t* flags, uint64_t* n_in, uint64_t max_chunks) {
-    *n_out = 0; *flags = 0; *result = work;
+// keys[0..n) ordered by their TOP b bits (of key_bits) -> the distinct keys with their counts, SORTED.  Two steps, because the
+// caller can only size the result once the first is done:
+//   dedupe_pass   counts the blocks (dedupe_kernel): words in `work` (at least as many words as keys), block by block.
+//                 *flags: bit 0 = some table filled up (the words are not to be used), bit 1 = some counts went to the side list.
+//                 max_chunks > 0: only the leading blocks (the sample; *n_in = the keys they cover).
+//   dedupe_finish moves the words together and apart into out_k / out_c (r.n_out entries each).
+int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int pack, u64* work, uint64_t cap, DedupeResult* r,
+                uint64_t* n_in, uint64_t max_chunks) {
+    *r = DedupeResult();
     if (n_in) *n_in = n;
     if (n == 0) return ZK_OK;
-    if (shift < 1 || shift > 24 || pack < 10 || pack > 31) return fail(c, ZK_EINTERNAL, "dedupe_pass: shift %d, pack %d", shift, pack);
+    if (b < 1 || b > 24 || b >= key_bits || pack < 10 || pack > 31) return fail(c, ZK_EINTERNAL, "dedupe_pass: %d block bits of %d, pack %d", b, key_bits, pack);
     if (cap < n) return fail(c, ZK_ENOSPC, "dedupe_pass: work buffer of %llu words for %llu keys", (unsigned long long)cap, (unsigned long long)n);
     DedupeArgs a = {};
-    uint64_t chunks = 1ull << shift;          // one workgroup per block
-    const bool sample = max_chunks > 0;          // counted only, never moved: the keys stay as they are
-    if (sample && chunks > max_chunks) chunks = max_chunks;
-    u64 *cuts, *nwords, *incl;
+    uint64_t chunks = 1ull << b;          // one block per value of the top bits
+    if (max_chunks && chunks > max_chunks) chunks = max_chunks;
+    u64 *cuts, *nwords, *incl, *big;
+    const u32 big_cap = 1u << 16;
     ZK_TRY(arena_alloc(c, sizeof(u64) * (chunks + 1), (void**)&cuts));
     ZK_TRY(arena_alloc(c, sizeof(u64) * chunks, (void**)&nwords));
     ZK_TRY(arena_alloc(c, sizeof(u64) * chunks, (void**)&incl));
-    hipLaunchKernelGGL(dedupe_cuts_kernel, dim3((u32)div_up(chunks + 1, 256)), dim3(256), 0, c->stream, keys, (u64)n, shift, (u32)chunks, cuts);
-    a.kin = keys; a.n = n; a.cuts = cuts; a.out = work; a.nwords = nwords; a.shift = shift; a.pack = pack;
+    ZK_TRY(arena_alloc(c, sizeof(u64) * 2 * big_cap, (void**)&big));
+    a.tag_bits = key_bits - b;
+    hipLaunchKernelGGL(dedupe_cuts_kernel, dim3((u32)div_up(chunks + 1, 256)), dim3(256), 0, c->stream, keys, (u64)n, a.tag_bits, (u32)chunks, cuts);
+    a.kin = keys; a.n = n; a.cuts = cuts; a.out = work; a.nwords = nwords; a.pack = pack;
     a.chunks = (u32)chunks;
     a.flags = (u32*)(c->d_scalars + 27);
     a.counter = (u32*)(c->d_scalars + 29);
-    ZK_HIP(c, hipMemsetAsync(c->d_scalars + 27, 0, 3 * sizeof(u64), c->stream));
+    a.n_big = (u32*)(c->d_scalars + 30);
+    a.big = big; a.big_cap = big_cap;
+    ZK_HIP(c, hipMemsetAsync(c->d_scalars + 27, 0, 4 * sizeof(u64), c->stream));
     prof_begin(c, ZK_PROF_RLE, 8 * n);
-    // 32-bit entries when the bits above `shift` fit
     const u32 grid = chunks < (uint64_t)c->num_cus ? (u32)chunks : (u32)c->num_cus;
-    if (key_bits - shift <= 32) hipLaunchKernelGGL(dedupe_kernel<true>, dim3(grid), dim3(1024), 0, c->stream, a);
+    if (a.tag_bits <= 32) hipLaunchKernelGGL(dedupe_kernel<true>, dim3(grid), dim3(1024), 0, c->stream, a);
     else hipLaunchKernelGGL(dedupe_kernel<false>, dim3(grid), dim3(1024), 0, c->stream, a);
+    prof_end(c);
     ZK_HIP(c, hipGetLastError());
     ZK_HIP(c, hipMemcpyAsync(incl, nwords, sizeof(u64) * chunks, hipMemcpyDeviceToDevice, c->stream));
     ZK_TRY(scan64_inclusive(c, incl, chunks));
-    // the keys are consumed: the words are moved together into their buffer (sample: nothing is moved, only counted)
-    if (!sample) {
-        hipLaunchKernelGGL(dedupe_pack_kernel, dim3((u32)c->num_cus * 8), dim3(256), 0, c->stream, work, cuts, incl, nwords, (u32)chunks, keys);
-        *result = keys;
-    }
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, incl + chunks - 1, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 27, c->d_scalars + 27, 4 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 31, cuts + chunks, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_TRY(check_device_error(c));
+    r->n_out = c->h_scalars[9];
+    r->flags = (uint32_t)c->h_scalars[27];
+    r->n_big = (uint32_t)c->h_scalars[30];
+    if (r->n_big > big_cap) r->flags |= 1;          // more counts beyond the field than the side list holds: the long way
+    r->cuts = cuts; r->nwords = nwords; r->incl = incl; r->big = big; r->chunks = (uint32_t)chunks; r->pack = pack; r->work = work;
+    if (n_in) *n_in = c->h_scalars[31];          // keys covered by the blocks that were counted
+    return ZK_OK;
+}
+
+int dedupe_finish(zk_ctx* c, const DedupeResult& r, u64* out_k, u32* out_c) {
+    if (r.n_out == 0) return ZK_OK;
+    prof_begin(c, ZK_PROF_SELECT, 20 * r.n_out);
+    hipLaunchKernelGGL(dedupe_unpack_kernel, dim3((u32)c->num_cus * 8), dim3(256), 0, c->stream, r.work, r.cuts, r.incl, r.nwords, r.chunks, r.pack, out_k, out_c);
+    if (r.n_big) hipLaunchKernelGGL(dedupe_big_kernel, dim3((r.n_big + 255) / 256), dim3(256), 0, c->stream, r.big, r.n_big, out_k, (u64)r.n_out, out_c, c->d_err);
     prof_end(c);
     ZK_HIP(c, hipGetLastError());
-    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, incl + chunks - 1, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 27, c->d_scalars + 27, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 28, cuts + chunks, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    ZK_TRY(check_device_error(c));
-    *n_out = c->h_scalars[9];
-    *flags = (uint32_t)c->h_scalars[27];
-    if (n_in) *n_in = c->h_scalars[28];          // keys covered by the blocks that were counted
     return ZK_OK;
 }
 
