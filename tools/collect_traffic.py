@@ -21,7 +21,7 @@ for name in f:
         fk, wk = sum(f[name]) / len(f[name]), sum(w[name]) / len(w[name])
         out[name] = dict(launches=len(f[name]), fetch_size_kib=fk, write_size_kib=wk,
                          traffic_bytes_per_launch=(2 * fk + wk) * 1024,
-                         n_keys=(int(sys.argv[4]) if len(sys.argv) > 4 and "pass_pipe_kernel" in name and name.rstrip().endswith(", 0, 0>(zk::SortArgs, unsigned int)") else None))
+                         n_keys=(int(sys.argv[4]) if len(sys.argv) > 4 and "pass_pipe_kernel" in name and (name.rstrip().endswith(", 0, 0>(zk::SortArgs, unsigned int)") or name.rstrip().endswith(", 1, 0>(zk::SortArgs, unsigned int)")) else None))
 import bench     # the hash of the kernel sources the profile was taken from: bench.py quotes a row only while it matches
 out["_kernel_source_sha256"] = bench.kernel_source_hash()
 json.dump(out, open(sys.argv[3], "w"), indent=1)
