@@ -457,6 +457,29 @@ def test_kmerize_large_properties(ctx):
     assert np.array_equal(k3.to_host(), w["kmers"]) and np.array_equal(c3.to_host(), w["counts"])
 
 
+def test_kmerize_large_without_repeats(ctx):
+    """4.1 M random reads (no genome: hardly a k-mer occurs twice): the histogram kernel's look before the sort -- four whole
+    blocks of the block dedupe set aside and counted -- must decline the top-bits-first plan, and the result must be that of the
+    plain full-width sort and carry the stream's checksums."""
+    R, L, K = 4_100_000, 150, 25
+    d = ctx.synth_reads(synth.DEFAULT_SEED + 1, 0, R, L, genome=0, n_thr=synth.frac32(0.0005))
+    want = ctx.stream_checksum(d, K)
+    ctx.profile(True)
+    k, c, st = ctx.kmerize(d, K, native.KMERIZE_CANONICAL, cap=2 * R * (L - K + 1) + 16)
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    assert ctx.checksum(k, c) == want and st.n_instances == want[0]
+    assert prof["hist_stream"]["launches"] == 2 and prof["pass_stream"]["launches"] == 1, "declined before any pass, then planned again"
+    kh = k.to_host()
+    assert np.all(kh[1:] > kh[:-1])
+    ctx.tune(early_collapse=0)
+    try:
+        k0, c0, _ = ctx.kmerize(d, K, native.KMERIZE_CANONICAL, cap=len(kh) + 16)
+        assert np.array_equal(k0.to_host(), kh) and np.array_equal(c0.to_host(), c.to_host())
+    finally:
+        ctx.tune(early_collapse=1)
+
+
 # ---- K5/K6 union-sum ----------------------------------------------------------------------------------------------
 
 def test_merge_golden(ctx):

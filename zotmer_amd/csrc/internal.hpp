@@ -118,7 +118,11 @@ int sort_pairs_upper(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint6
 int sort_pairs_mirrored(zk_ctx* c, const u64* src_k, const u32* src_v, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int K,
                         u64** rk, u32** rv);
 // sort whose first pass generates the keys from a base stream (encode.hip + radix_sort.hip)
-struct StreamSrc { const u8* stream; uint64_t n_bytes; int K; int mode; int lo_bit; int hi_bit = 0; };   // mode: ZK_KEYS_*; sort bits [lo_bit, hi_bit) (hi_bit 0 = 2K)
+// Ask sort_stream to look before it sorts: the histogram kernel sets aside the keys whose bits from `shift` up equal `value` (a
+// few whole blocks of the block dedupe: every copy of their k-mers), and if more than max_ratio of them are distinct the sort is
+// declined (return 1, nothing sorted) -- the caller then plans for an input that does not repeat its k-mers.
+struct StreamSample { int shift; uint64_t value; double max_ratio; uint64_t seen = 0, distinct = 0; };
+struct StreamSrc { const u8* stream; uint64_t n_bytes; int K; int mode; int lo_bit; int hi_bit = 0; StreamSample* sample = nullptr; };   // mode: ZK_KEYS_*; sort bits [lo_bit, hi_bit) (hi_bit 0 = 2K)
 int sort_rbits(zk_ctx* c);
 int sort_first_bits(zk_ctx* c, int key_bits, int lo_bit);
 struct DedupeResult {

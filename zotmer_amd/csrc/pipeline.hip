@@ -241,11 +241,23 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
         const int b = rb * passes;
         if (b < fused_bit + rb && b + rb / 2 < 2 * K && b <= 24 && (n_bytes >> b) >= 2048) dedupe_bit = b;
     }
-    if (dedupe_bit) { src.lo_bit = 2 * K - dedupe_bit; src.hi_bit = 0; }
-    else src.hi_bit = fused_bit ? fused_bit : collapse_bit;
     uint64_t n = 0;
     u64* sorted = nullptr;
-    ZK_TRY(sort_stream(c, src, buf_a, buf_b, cap_keys, &n, st->acgt, &sorted));
+    if (dedupe_bit) {
+        // Sorting the top bits first only pays if the blocks can then be counted; an input that does not repeat its k-mers would
+        // have to start over.  So the histogram kernel sets aside four whole blocks (prefixes AAATCCTA.: every copy of their
+        // k-mers) and the sort is declined when they show little duplication -- at the price of one more histogram run.
+        StreamSample smp{2 * K - dedupe_bit + 2, (uint64_t)(0x0D71C8E5u >> (32 - (dedupe_bit - 2))), 0.6};
+        src.lo_bit = 2 * K - dedupe_bit; src.hi_bit = 0; src.sample = &smp;
+        const int rc = sort_stream(c, src, buf_a, buf_b, cap_keys, &n, st->acgt, &sorted);
+        if (rc < 0) return rc;
+        src.sample = nullptr;
+        if (rc == 1) { dedupe_bit = 0; src.lo_bit = 0; }
+    }
+    if (!dedupe_bit) {
+        src.hi_bit = fused_bit ? fused_bit : collapse_bit;
+        ZK_TRY(sort_stream(c, src, buf_a, buf_b, cap_keys, &n, st->acgt, &sorted));
+    }
     st->n_windows = both ? n / 2 : n;
     st->n_instances = both ? n : 2 * n;
     *n_out = 0;

@@ -206,6 +206,11 @@ struct HistArgs {
     u32 tiles;
     u64* rec_info;       // PRE only: [0] = position of the stream's first newline (read), [1] += newline bytes,
                          // [2] += 16-byte chunks whose newlines are not exactly the record separators
+    u64* sample;         // PRE only, or null: keys with (key >> sample_shift) == sample_value are also appended here ...
+    u32* sample_n;       // ... += 1 each (appended while below sample_cap)
+    u32 sample_cap;
+    int sample_shift;
+    u64 sample_value;
 };
 
 // position of the first '\n' in the head of the stream (~0 if there is none): the record length, if records are uniform
@@ -333,6 +338,10 @@ __global__ __launch_bounds__(C::BLOCK, PRE ? 8 : 1) void hist_kernel(HistArgs h)
                                 const u32 d = (u32)(kk >> h.plan.shift[p]) & ((1u << h.plan.bits[p]) - 1u);
                                 atomicAdd(&bins[p * C::RADIX + d], 1u);
                             }
+                        }
+                        if (h.sample && (kk >> h.sample_shift) == h.sample_value) {
+                            const u32 at = atomicAdd(h.sample_n, 1u);
+                            if (at < h.sample_cap) h.sample[at] = kk;
                         }
                     }
                 }
@@ -1664,8 +1673,12 @@ struct Sorter {
     }
 
     template <int SRC>
-    static int launch_hist(zk_ctx* c, const SortArgs& src, const PassPlan& plan, u64* ghist, u64* acgt, u64* d_n) {
+    static int launch_hist(zk_ctx* c, const SortArgs& src, const PassPlan& plan, u64* ghist, u64* acgt, u64* d_n,
+                           u64* sample = nullptr, u32 sample_cap = 0, int sample_shift = 0, u64 sample_value = 0) {
         HistArgs h;
+        h.sample = sample; h.sample_cap = sample_cap; h.sample_shift = sample_shift; h.sample_value = sample_value;
+        h.sample_n = (u32*)(c->d_scalars + 23);
+        if (sample) ZK_HIP(c, hipMemsetAsync(c->d_scalars + 23, 0, sizeof(u64), c->stream));
         h.src = src;
         h.plan = plan;
         h.ghist = ghist;
@@ -1753,7 +1766,11 @@ struct Sorter {
         a.stream = src.stream; a.n_bytes = src.n_bytes; a.K = src.K; a.mode = src.mode;
         u64* d_acgt = c->d_scalars + 0;
         u64* d_n = c->d_scalars + 8;
-        ZK_TRY(launch_hist<SRC_STREAM>(c, a, plan, ghist, d_acgt, d_n));
+        // the look before the sort (StreamSample): the set-aside keys go to the second sort buffer, which is idle until pass 1
+        const u32 sample_cap = 1u << 20;
+        const bool sampling = src.sample && cap >= 4ull * sample_cap && src.mode == ZK_KEYS_CANONICAL;
+        ZK_TRY(launch_hist<SRC_STREAM>(c, a, plan, ghist, d_acgt, d_n, sampling ? buf_b : nullptr, sample_cap,
+                                       sampling ? src.sample->shift : 0, sampling ? src.sample->value : 0));
         // the number of live keys decides the grids of the array passes: one small readback
         ZK_HIP(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(u64) * 24, hipMemcpyDeviceToHost, c->stream));
         ZK_HIP(c, hipStreamSynchronize(c->stream));
@@ -1762,6 +1779,19 @@ struct Sorter {
         *n_keys = n;
         if (n > cap) return fail(c, ZK_ENOSPC, "sort buffers hold %llu keys, the stream has %llu", (unsigned long long)cap, (unsigned long long)n);
         if (n == 0) return ZK_OK;
+        if (sampling) {
+            uint64_t sn = c->h_scalars[23] & 0xffffffffull;
+            if (sn > sample_cap) sn = sample_cap;
+            src.sample->seen = sn;
+            if (sn >= 4096) {          // enough to judge
+                u64* res = nullptr;
+                uint64_t distinct = 0;
+                ZK_TRY(sort_keys(c, buf_b, buf_b + sample_cap, sn, 2 * src.K, &res));
+                ZK_TRY(rle(c, res, sn, res, (u32*)(buf_b + 2ull * sample_cap), sn, &distinct));
+                src.sample->distinct = distinct;
+                if ((double)distinct > src.sample->max_ratio * (double)sn) return 1;          // declined: nothing sorted
+            }
+        }
         a.kout = buf_a; a.shift = plan.shift[0]; a.bits = plan.bits[0]; a.ghist = ghist;
         a.n = n;
         if constexpr (C::PIPE && C::ITEMS == 16 && PipeSmem<C>::IMG_FITS && C::BLOCK <= 512) {
