@@ -986,24 +986,57 @@ __global__ void dedupe_cuts_kernel(const u64* __restrict__ k, u64 n, int tag_bit
     cuts[v] = lo;
 }
 
+// what a workgroup carries from one block to the next: the block it is about to count, with the first tile of its keys already
+// asked for -- the ticket, the bounds and those keys travel while the previous block is being sorted and written
+template <int ITEMS>
+struct DedupeNext {
+    u32 chunk;
+    u64 lo, hi;
+    u64 key[ITEMS];
+};
+
 template <bool TAG32>
-__device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG32>& sm, const u32 chunk) {
+__device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG32>& sm, DedupeNext<DedupeSmem<TAG32>::ITEMS>& st) {
     using S = DedupeSmem<TAG32>;
     using E = typename S::E;
     constexpr int BLOCK = S::BLOCK, ITEMS = S::ITEMS, TILE = S::TILE, ALL = S::ALL, SPT = S::SPT, NB = S::NB;
     constexpr E EMPTY = (E)~(E)0;            // no entry.  A 64-bit tag never has all its bits set; a 32-bit one may: see `home`
     constexpr u32 HS = TAG32 ? ALL - 1 : ALL;          // ... then the last entry belongs to the all-ones tag alone
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const u64 lo = a.cuts[chunk], hi = a.cuts[chunk + 1];
+    const u32 chunk = st.chunk;
+    const u64 lo = st.lo, hi = st.hi;
     const u32 maxc = (1u << a.pack) - 1u;
+    // whole tiles: one address, constant offsets; the cut last tile: per-key bounds
+    auto load = [&](u64 base, u64 end, u64 (&k)[ITEMS]) {
+        if (base + TILE <= end) {
+            const u64* p = a.kin + base + tid;
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) k[i] = p[i * BLOCK];
+        } else {
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const u64 g = base + (u64)i * BLOCK + tid;
+                k[i] = g < end ? a.kin[g] : ~0ull;
+            }
+        }
+    };
+    if (tid == 0) sm.ticket = atomicAdd(a.counter, 1u);          // the block after this one: read after the next barrier
     if (hi <= lo) {
         if (tid == 0) a.nwords[chunk] = 0;
+        __syncthreads();
+        st.chunk = (u32)__builtin_amdgcn_readfirstlane((int)sm.ticket);
+        st.lo = st.hi = 0;
+        if (st.chunk < a.chunks) { st.lo = a.cuts[st.chunk]; st.hi = a.cuts[st.chunk + 1]; }
+        if (st.hi > st.lo) load(st.lo, st.hi, st.key);
         return;
     }
     for (int q = tid; q < ALL * (int)sizeof(E) / 16; q += BLOCK) reinterpret_cast<uint4*>(sm.keys)[q] = make_uint4(~0u, ~0u, ~0u, ~0u);
     for (int q = tid; q < ALL / 4; q += BLOCK) reinterpret_cast<uint4*>(sm.cnt)[q] = make_uint4(0, 0, 0, 0);
     if (tid < NB) { sm.bc[tid] = 0; sm.bfill[tid] = 0; }
     __syncthreads();
+    const u32 nchunk = (u32)__builtin_amdgcn_readfirstlane((int)sm.ticket);
+    u64 nlo = 0, nhi = 0;
+    if (nchunk < a.chunks) { nlo = a.cuts[nchunk]; nhi = a.cuts[nchunk + 1]; }
     u32 bad = 0;
     // The kernel is bound by its instruction count (188 per key with several keys probing at once, 88 with one tight probing
     // loop per key -- a loop runs as long as the unluckiest of its 64 lanes).  So the common case has NO loop and no branch:
@@ -1044,7 +1077,7 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
     auto insert = [&](u64 k, bool valid) {
         const E e = (E)(k & tmask);
         const u32 h = home(e);
-        const E old = valid ? cas(h, e) : e;
+        const E old = valid ? cas(h, e) : e;          // (a plain read first, the swap only for the lanes that see "empty": no faster)
         const bool ok = old == EMPTY || old == e;
         atomicAdd(&sm.cnt[h], (ok && valid) ? 1u : 0u);
         const u64 m = __ballot(!ok);
@@ -1054,23 +1087,10 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
         }
     };
     u64 key[ITEMS], nk[ITEMS];
-    // whole tiles: one address, constant offsets; the cut last tile: per-key bounds
-    auto load = [&](u64 base, u64 (&k)[ITEMS]) {
-        if (base + TILE <= hi) {
-            const u64* p = a.kin + base + tid;
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++) k[i] = p[i * BLOCK];
-        } else {
-#pragma unroll
-            for (int i = 0; i < ITEMS; i++) {
-                const u64 g = base + (u64)i * BLOCK + tid;
-                k[i] = g < hi ? a.kin[g] : ~0ull;
-            }
-        }
-    };
-    load(lo, key);
+    for (int i = 0; i < ITEMS; i++) key[i] = st.key[i];          // the first tile was asked for during the previous block
     for (u64 base = lo; base < hi; base += TILE) {
-        if (base + TILE < hi) load(base + TILE, nk);
+        if (base + TILE < hi) load(base + TILE, hi, nk);
         if (base + TILE <= hi) {
 #pragma unroll
             for (int i = 0; i < ITEMS; i++) insert(key[i], true);
@@ -1083,6 +1103,8 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
         if (nside > (u32)S::SIDE_KEEP || base + TILE >= hi) drain();
     }
     if (bad) { atomicOr(a.flags, 1u); a.flags[1] = chunk; }          // (the second word: one of the blocks it happened in, for diagnosis)
+    st.chunk = nchunk; st.lo = nlo; st.hi = nhi;
+    if (nhi > nlo) load(nlo, nhi, st.key);          // the next block's first tile travels while this one is sorted and written
     __syncthreads();
     // ---- the block's entries, sorted: a counting sort on the tag's top byte, then ranks inside each byte's group ---------
     // thread t takes the entries t, t + BLOCK, ... into registers; the table's memory then takes them back grouped
@@ -1141,13 +1163,22 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
 // the sizes go with the first bases, a stride of the grid would give one workgroup all the big ones.
 template <bool TAG32>
 __global__ __launch_bounds__(1024, 4) void dedupe_kernel(DedupeArgs a) {
-    __shared__ DedupeSmem<TAG32> sm;
-    for (;;) {
-        if (threadIdx.x == 0) sm.ticket = atomicAdd(a.counter, 1u);
-        __syncthreads();
-        const u32 chunk = (u32)__builtin_amdgcn_readfirstlane((int)sm.ticket);
-        if (chunk >= a.chunks) break;
-        dedupe_block<TAG32>(a, sm, chunk);
+    using S = DedupeSmem<TAG32>;
+    __shared__ S sm;
+    DedupeNext<S::ITEMS> st;
+    if (threadIdx.x == 0) sm.ticket = atomicAdd(a.counter, 1u);
+    __syncthreads();
+    st.chunk = (u32)__builtin_amdgcn_readfirstlane((int)sm.ticket);
+    st.lo = st.hi = 0;
+    if (st.chunk < a.chunks) { st.lo = a.cuts[st.chunk]; st.hi = a.cuts[st.chunk + 1]; }
+#pragma unroll
+    for (int i = 0; i < S::ITEMS; i++) {
+        const u64 g = st.lo + (u64)i * S::BLOCK + threadIdx.x;
+        st.key[i] = g < st.hi ? a.kin[g] : ~0ull;
+    }
+    __syncthreads();          // the ticket word is free again
+    while (st.chunk < a.chunks) {
+        dedupe_block<TAG32>(a, sm, st);          // leaves the next block in st
         __syncthreads();          // the table and the ticket word are free again
     }
 }
