@@ -93,6 +93,7 @@ int zk_tune(zk_ctx* ctx, int what, int value);
 #define ZK_PROF_INTERSECT 10
 #define ZK_PROF_COUNT_HIST 11
 #define ZK_PROF_PASS_PACKED 12  /* radix pass of the key kernel over a collapsed list of (k-mer << s | count) words (16 B per word) */
+#define ZK_PROF_SAMPLE 13       /* the look before the sort: the few set-aside blocks, sorted and counted (tiny launches) */
 int zk_debug_buffer(zk_ctx* ctx, void* d_buf);   /* diagnostic builds (-DZK_STAMPS) only; NULL turns it off */
 int zk_profile(zk_ctx* ctx, int enable);   /* clears the records; enable != 0 starts recording */
 int zk_profile_read(zk_ctx* ctx, int tag, uint64_t* launches, double* total_ms, uint64_t* algorithmic_bytes);

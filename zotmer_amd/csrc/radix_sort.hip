@@ -1817,7 +1817,7 @@ struct Sorter {
             if (sn >= 4096) {          // enough to judge
                 u64* res = nullptr;
                 uint64_t distinct = 0;
-                ZK_TRY(sort_keys(c, buf_b, buf_b + sample_cap, sn, 2 * src.K, &res));
+                ZK_TRY(sort_keys(c, buf_b, buf_b + sample_cap, sn, 2 * src.K, &res, 0, ZK_PROF_SAMPLE));
                 ZK_TRY(rle(c, res, sn, res, (u32*)(buf_b + 2ull * sample_cap), sn, &distinct));
                 src.sample->distinct = distinct;
                 if ((double)distinct > src.sample->max_ratio * (double)sn) return 1;          // declined: nothing sorted

@@ -313,7 +313,7 @@ class Context:
 
     # ---- per-launch timing (HIP events on the ctx stream) -----------------------------------
     PROF_TAGS = {"hist_stream": 1, "hist_array": 2, "pass_stream": 3, "pass_keys": 4, "pass_pairs": 5, "rle": 6,
-                 "union_sum": 7, "select": 8, "mirror": 9, "intersect": 10, "count_hist": 11, "pass_packed": 12}
+                 "union_sum": 7, "select": 8, "mirror": 9, "intersect": 10, "count_hist": 11, "pass_packed": 12, "sample": 13}
 
     def tune(self, sort_variant=None, pairs_variant=None, short_sort=None, side_div=None, xcd_group=None, comm_chunk=None,
              early_collapse=None, packed_pairs=None, wide_tiles=None):
