@@ -271,6 +271,7 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     bool in_aux = false;          // the counted list lives in the aux region (collapse path): both sort buffers are free
     uint64_t max_count = 0;       // largest count of the list, when it came for free (packed reduce)
     bool have_max = false;
+    u64 *mwords = nullptr, *malt = nullptr;          // the mirrored words, grouped by their low MIRROR_GROUP_BITS, when dedupe_finish wrote them
     if (dedupe_bit && n) {
         const int pk = pack_bits_for(K);
         DedupeResult r;
@@ -286,7 +287,13 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
                 const uint64_t a8 = (8 * uc + 255) & ~255ull, a4 = (4 * uc + 255) & ~255ull;
                 char* aux;
                 ZK_TRY(aux_require(c, a8 + a4, &aux));
-                ZK_TRY(dedupe_finish(c, r, (u64*)aux, (u32*)(aux + a8)));
+                // Every count fits the field (the usual case) and both strands are wanted: the copy that closes the gaps also
+                // writes the mirrored words grouped by their low 18 bits -- the first stage of the mirror sort (mirror_union's
+                // grouping copy) for free; they go over the keys' buffer (the keys are counted, the words are in the other one).
+                const bool want_m = !(r.flags & 2) && !canonical_only && c->packed_pairs && dedupe_bit == MIRROR_GROUP_BITS &&
+                                    2 * K >= MIRROR_GROUP_BITS + 8;
+                ZK_TRY(dedupe_finish(c, r, (u64*)aux, (u32*)(aux + a8), want_m ? sorted : nullptr, K, MIRROR_GROUP_BASES));
+                if (want_m) { mwords = sorted; malt = other; }
                 sorted = (u64*)aux; cnt = (u32*)(aux + a8);
                 in_aux = true;
                 if (!(r.flags & 2)) { max_count = (1ull << pk) - 1; have_max = true; }          // every count fits the field
@@ -399,6 +406,12 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
         ZK_HIP(c, hipMemcpyAsync(out_c, cnt, 4 * uc, hipMemcpyDeviceToDevice, c->stream));
         *n_out = uc;
         return ZK_OK;
+    }
+    if (mwords) {
+        const int pk = pack_bits_for(K);
+        u64* sk = nullptr;
+        ZK_TRY(sort_keys_upper(c, mwords, malt, uc, 2 * K + pk, MIRROR_GROUP_BITS + pk, &sk));
+        return union_sum_packed_b(c, sorted, cnt, uc, sk, uc, pk, out_k, out_c, cap, n_out);
     }
     const uint64_t a8 = (8 * uc + 255) & ~255ull, a4 = (4 * uc + 255) & ~255ull;
     u64 *rk, *rk2; u32 *rv, *rv2;

@@ -1184,20 +1184,32 @@ __global__ __launch_bounds__(1024, 4) void dedupe_kernel(DedupeArgs a) {
 }
 
 // the words of the blocks, moved together and taken apart: block v's words -> keys / counts [incl[v] - nwords[v], incl[v])
+// out_m (or null): beside them the mirrored words (rc(key) << pack | count), already grouped by their low block bits -- block v of
+// the list IS group rc(v) of the mirror list (the first bases of a k-mer are the last of its reverse complement), and minc holds
+// the groups' inclusive ends: the first stage of the mirror sort comes for free with the copy that is made anyway.
 __global__ __launch_bounds__(256) void dedupe_unpack_kernel(const u64* __restrict__ in, const u64* __restrict__ cuts, const u64* __restrict__ incl,
                                                             const u64* __restrict__ nwords, u32 chunks, int pack, u64* __restrict__ out_k,
-                                                            u32* __restrict__ out_c) {
+                                                            u32* __restrict__ out_c, u64* __restrict__ out_m, const u64* __restrict__ minc,
+                                                            int K, int gbases) {
     const u64 maxc = (1ull << pack) - 1;
     for (u32 v = blockIdx.x; v < chunks; v += gridDim.x) {
         const u64 cnt = nwords[v];
         const u64 dst0 = incl[v] - cnt;
         const u64* src = in + cuts[v];
+        const u64 mdst = out_m ? minc[(u32)revcomp(gbases, (u64)v)] - cnt : 0;
         for (u64 i = threadIdx.x; i < cnt; i += blockDim.x) {
             const u64 w = src[i];
             out_k[dst0 + i] = w >> pack;
             out_c[dst0 + i] = (u32)(w & maxc);
+            if (out_m) out_m[mdst + i] = (revcomp(K, w >> pack) << pack) | (w & maxc);
         }
     }
+}
+
+// msz[g] = words of the block whose mirror image is group g
+__global__ void dedupe_mirror_sizes_kernel(const u64* __restrict__ nwords, u32 chunks, int gbases, u64* __restrict__ msz) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < chunks) msz[g] = nwords[(u32)revcomp(gbases, (u64)g)];
 }
 
 // the counts that did not fit a word: found again by key in the sorted list
@@ -1989,10 +2001,20 @@ int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int
     return ZK_OK;
 }
 
-int dedupe_finish(zk_ctx* c, const DedupeResult& r, u64* out_k, u32* out_c) {
+// out_m (or null; K odd or even, 2 * gbases block bits = all 4^gbases blocks counted): the mirrored words, grouped by their low
+// 2 * gbases bits (dedupe_unpack_kernel) -- ready for the passes over the bits above
+int dedupe_finish(zk_ctx* c, const DedupeResult& r, u64* out_k, u32* out_c, u64* out_m, int K, int gbases) {
     if (r.n_out == 0) return ZK_OK;
-    prof_begin(c, ZK_PROF_SELECT, 20 * r.n_out);
-    hipLaunchKernelGGL(dedupe_unpack_kernel, dim3((u32)c->num_cus * 8), dim3(256), 0, c->stream, r.work, r.cuts, r.incl, r.nwords, r.chunks, r.pack, out_k, out_c);
+    u64* minc = nullptr;
+    if (out_m) {
+        if ((1ull << (2 * gbases)) != r.chunks) return fail(c, ZK_EINTERNAL, "dedupe_finish: %u blocks are not 4^%d", r.chunks, gbases);
+        ZK_TRY(arena_alloc(c, sizeof(u64) * r.chunks, (void**)&minc));
+        hipLaunchKernelGGL(dedupe_mirror_sizes_kernel, dim3((r.chunks + 255) / 256), dim3(256), 0, c->stream, r.nwords, r.chunks, gbases, minc);
+        ZK_TRY(scan64_inclusive(c, minc, r.chunks));
+    }
+    prof_begin(c, ZK_PROF_SELECT, (out_m ? 28 : 20) * r.n_out);
+    hipLaunchKernelGGL(dedupe_unpack_kernel, dim3((u32)c->num_cus * 8), dim3(256), 0, c->stream, r.work, r.cuts, r.incl, r.nwords, r.chunks, r.pack, out_k, out_c,
+                       out_m, minc, K, gbases);
     if (r.n_big) hipLaunchKernelGGL(dedupe_big_kernel, dim3((r.n_big + 255) / 256), dim3(256), 0, c->stream, r.big, r.n_big, out_k, (u64)r.n_out, out_c, c->d_err);
     prof_end(c);
     ZK_HIP(c, hipGetLastError());
