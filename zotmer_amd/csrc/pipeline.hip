@@ -272,6 +272,7 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     uint64_t max_count = 0;       // largest count of the list, when it came for free (packed reduce)
     bool have_max = false;
     u64 *mwords = nullptr, *malt = nullptr;          // the mirrored words, grouped by their low MIRROR_GROUP_BITS, when dedupe_finish wrote them
+    u64* mhist = nullptr;                            // ... and the digit counts of the passes that sort them, when it took those as well
     if (dedupe_bit && n) {
         const int pk = pack_bits_for(K);
         DedupeResult r;
@@ -292,7 +293,7 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
                 // grouping copy) for free; they go over the keys' buffer (the keys are counted, the words are in the other one).
                 const bool want_m = !(r.flags & 2) && !canonical_only && c->packed_pairs && dedupe_bit == MIRROR_GROUP_BITS &&
                                     2 * K >= MIRROR_GROUP_BITS + 8;
-                ZK_TRY(dedupe_finish(c, r, (u64*)aux, (u32*)(aux + a8), want_m ? sorted : nullptr, K, MIRROR_GROUP_BASES));
+                ZK_TRY(dedupe_finish(c, r, (u64*)aux, (u32*)(aux + a8), want_m ? sorted : nullptr, K, MIRROR_GROUP_BASES, &mhist));
                 if (want_m) { mwords = sorted; malt = other; }
                 sorted = (u64*)aux; cnt = (u32*)(aux + a8);
                 in_aux = true;
@@ -410,7 +411,8 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     if (mwords) {
         const int pk = pack_bits_for(K);
         u64* sk = nullptr;
-        ZK_TRY(sort_keys_upper(c, mwords, malt, uc, 2 * K + pk, MIRROR_GROUP_BITS + pk, &sk));
+        if (mhist) ZK_TRY(sort_keys_upper_counted(c, mwords, malt, uc, 2 * K + pk, MIRROR_GROUP_BITS + pk, mhist, &sk));
+        else ZK_TRY(sort_keys_upper(c, mwords, malt, uc, 2 * K + pk, MIRROR_GROUP_BITS + pk, &sk));
         return union_sum_packed_b(c, sorted, cnt, uc, sk, uc, pk, out_k, out_c, cap, n_out);
     }
     const uint64_t a8 = (8 * uc + 255) & ~255ull, a4 = (4 * uc + 255) & ~255ull;

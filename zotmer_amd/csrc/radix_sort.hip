@@ -1187,10 +1187,18 @@ __global__ __launch_bounds__(1024, 4) void dedupe_kernel(DedupeArgs a) {
 // out_m (or null): beside them the mirrored words (rc(key) << pack | count), already grouped by their low block bits -- block v of
 // the list IS group rc(v) of the mirror list (the first bases of a k-mer are the last of its reverse complement), and minc holds
 // the groups' inclusive ends: the first stage of the mirror sort comes for free with the copy that is made anyway.
+struct MirrorHist { int passes; int shift[4]; int bits[4]; u64* raw; };          // raw: [passes][512] digit counts of the mirrored words, += here
+
 __global__ __launch_bounds__(256) void dedupe_unpack_kernel(const u64* __restrict__ in, const u64* __restrict__ cuts, const u64* __restrict__ incl,
                                                             const u64* __restrict__ nwords, u32 chunks, int pack, u64* __restrict__ out_k,
                                                             u32* __restrict__ out_c, u64* __restrict__ out_m, const u64* __restrict__ minc,
-                                                            int K, int gbases) {
+                                                            int K, int gbases, MirrorHist mh) {
+    __shared__ u32 bins[4 * 512];          // the digit histograms of the mirror sort's passes: it reads every word anyway
+    const bool hist = out_m && mh.passes > 0;
+    if (hist) {
+        for (int q = threadIdx.x; q < 4 * 512; q += blockDim.x) bins[q] = 0;
+        __syncthreads();
+    }
     const u64 maxc = (1ull << pack) - 1;
     for (u32 v = blockIdx.x; v < chunks; v += gridDim.x) {
         const u64 cnt = nwords[v];
@@ -1201,8 +1209,21 @@ __global__ __launch_bounds__(256) void dedupe_unpack_kernel(const u64* __restric
             const u64 w = src[i];
             out_k[dst0 + i] = w >> pack;
             out_c[dst0 + i] = (u32)(w & maxc);
-            if (out_m) out_m[mdst + i] = (revcomp(K, w >> pack) << pack) | (w & maxc);
+            if (out_m) {
+                const u64 mw = (revcomp(K, w >> pack) << pack) | (w & maxc);
+                out_m[mdst + i] = mw;
+                if (hist) {
+#pragma unroll
+                    for (int p = 0; p < 4; p++)
+                        if (p < mh.passes) atomicAdd(&bins[p * 512 + ((u32)(mw >> mh.shift[p]) & ((1u << mh.bits[p]) - 1u))], 1u);
+                }
+            }
         }
+    }
+    if (hist) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < mh.passes * 512; q += blockDim.x)
+            if (bins[q]) atomicAdd(&mh.raw[q], (u64)bins[q]);
     }
 }
 
@@ -1752,14 +1773,21 @@ struct Sorter {
     }
 
     // lo_bit > 0: only the bits [lo_bit, key_bits) are sorted (the input is already ordered by the bits below)
-    static int sort_keys(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** result, int lo_bit = 0, int prof_tag = 0) {
+    // counted: [passes][RADIX] raw digit counts that the producer of `keys` took on the way (no histogram pass of its own)
+    static int sort_keys(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** result, int lo_bit = 0, int prof_tag = 0,
+                         u64* counted = nullptr) {
         PassPlan plan = make_plan(key_bits - lo_bit, C::RBITS, lo_bit);
-        u64* ghist;
-        ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * C::RADIX, (void**)&ghist));
+        u64* ghist = counted;
+        if (!counted) ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * C::RADIX, (void**)&ghist));
         SortArgs a = {};
         a.kin = keys; a.n = n;
         a.prof_tag = prof_tag;      // the upper-bit passes over collapsed / packed lists are timed apart
-        ZK_TRY(launch_hist<SRC_ARRAY>(c, a, plan, ghist, nullptr, c->d_scalars + 8));
+        if (counted) {
+            hipLaunchKernelGGL(hist_scan_kernel, dim3(1), dim3(256), 0, c->stream, ghist, plan.passes, (int)C::RADIX, c->d_scalars + 8);
+            ZK_HIP(c, hipGetLastError());
+        } else {
+            ZK_TRY(launch_hist<SRC_ARRAY>(c, a, plan, ghist, nullptr, c->d_scalars + 8));
+        }
         u64* in = keys; u64* out = alt;
         for (int p = 0; p < plan.passes; p++) {
             a.kin = in; a.kout = out; a.shift = plan.shift[p]; a.bits = plan.bits[p];
@@ -1923,6 +1951,13 @@ int sort_keys_upper(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, in
     ZK_SORT_DISPATCH(c, sort_keys(c, keys, alt, n, key_bits, result, lo_bit, prof_tag));
 }
 
+// ... with the digit counts already taken (dedupe_finish; default geometry only)
+int sort_keys_upper_counted(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, int lo_bit, u64* counted, u64** result) {
+    *result = keys;
+    if (n == 0 || lo_bit >= key_bits) return ZK_OK;
+    return Sorter<V3>::sort_keys(c, keys, alt, n, key_bits, result, lo_bit, ZK_PROF_PASS_PACKED, counted);
+}
+
 // pairs already ordered by their low `lo_bit` bits: LSD passes over the bits above only
 int sort_pairs_upper(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, int lo_bit, u64** rk, u32** rv) {
     *rk = keys; *rv = vals;
@@ -2003,9 +2038,22 @@ int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int
 
 // out_m (or null; K odd or even, 2 * gbases block bits = all 4^gbases blocks counted): the mirrored words, grouped by their low
 // 2 * gbases bits (dedupe_unpack_kernel) -- ready for the passes over the bits above
-int dedupe_finish(zk_ctx* c, const DedupeResult& r, u64* out_k, u32* out_c, u64* out_m, int K, int gbases) {
+int dedupe_finish(zk_ctx* c, const DedupeResult& r, u64* out_k, u32* out_c, u64* out_m, int K, int gbases, u64** mirror_hist) {
+    if (mirror_hist) *mirror_hist = nullptr;
     if (r.n_out == 0) return ZK_OK;
     u64* minc = nullptr;
+    MirrorHist mh = {};
+    if (out_m && mirror_hist && c->sort_variant == 3) {
+        // the digit counts of the passes that will sort the mirrored words above their group bits (sort_keys_upper_counted)
+        const PassPlan plan = make_plan(2 * K - 2 * gbases, V3::RBITS, 2 * gbases + r.pack);
+        if (plan.passes <= 4) {
+            ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * V3::RADIX, (void**)&mh.raw));
+            ZK_HIP(c, hipMemsetAsync(mh.raw, 0, sizeof(u64) * MAX_PASSES * V3::RADIX, c->stream));
+            mh.passes = plan.passes;
+            for (int p = 0; p < plan.passes; p++) { mh.shift[p] = plan.shift[p]; mh.bits[p] = plan.bits[p]; }
+            *mirror_hist = mh.raw;
+        }
+    }
     if (out_m) {
         if ((1ull << (2 * gbases)) != r.chunks) return fail(c, ZK_EINTERNAL, "dedupe_finish: %u blocks are not 4^%d", r.chunks, gbases);
         ZK_TRY(arena_alloc(c, sizeof(u64) * r.chunks, (void**)&minc));
@@ -2014,7 +2062,7 @@ int dedupe_finish(zk_ctx* c, const DedupeResult& r, u64* out_k, u32* out_c, u64*
     }
     prof_begin(c, ZK_PROF_SELECT, (out_m ? 28 : 20) * r.n_out);
     hipLaunchKernelGGL(dedupe_unpack_kernel, dim3((u32)c->num_cus * 8), dim3(256), 0, c->stream, r.work, r.cuts, r.incl, r.nwords, r.chunks, r.pack, out_k, out_c,
-                       out_m, minc, K, gbases);
+                       out_m, minc, K, gbases, mh);
     if (r.n_big) hipLaunchKernelGGL(dedupe_big_kernel, dim3((r.n_big + 255) / 256), dim3(256), 0, c->stream, r.big, r.n_big, out_k, (u64)r.n_out, out_c, c->d_err);
     prof_end(c);
     ZK_HIP(c, hipGetLastError());
