@@ -130,13 +130,14 @@ struct DedupeResult {
     uint32_t flags = 0;          // bit 0: a table filled up (unusable), bit 1: counts beyond the packed field exist (patched by dedupe_finish)
     uint32_t n_big = 0;
     u64 *cuts = nullptr, *nwords = nullptr, *incl = nullptr, *big = nullptr, *work = nullptr;
+    u32* sub = nullptr;          // [chunks][64] or null: how a block's entries split on the 6 bits after the block bits
     uint32_t chunks = 0;
     int pack = 0;
 };
 int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int pack, u64* work, uint64_t cap, DedupeResult* r,
                 uint64_t* n_in = nullptr, uint64_t max_chunks = 0);
 int dedupe_finish(zk_ctx* c, const DedupeResult& r, u64* out_k, u32* out_c, u64* out_m = nullptr, int K = 0, int gbases = 0,
-                  u64** mirror_hist = nullptr);
+                  u64** mirror_hist = nullptr, int* mirror_group_bits = nullptr);
 int sort_keys_upper_counted(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, int lo_bit, u64* counted, u64** result);
 int collapse_pass(zk_ctx* c, const u64* keys, uint64_t n, int shift, int bits, int pack, u64* out, uint64_t cap, uint64_t* n_out,
                   uint64_t max_tiles = 0);

@@ -243,6 +243,7 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     }
     uint64_t n = 0;
     u64* sorted = nullptr;
+    bool presampled = false;
     if (dedupe_bit) {
         // Sorting the top bits first only pays if the blocks can then be counted; an input that does not repeat its k-mers would
         // have to start over.  So the histogram kernel sets aside four whole blocks (prefixes AAATCCTA.: every copy of their
@@ -253,6 +254,7 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
         if (rc < 0) return rc;
         src.sample = nullptr;
         if (rc == 1) { dedupe_bit = 0; src.lo_bit = 0; }
+        presampled = smp.seen >= 4096;          // the look was conclusive: no second one after the passes
     }
     if (!dedupe_bit) {
         src.hi_bit = fused_bit ? fused_bit : collapse_bit;
@@ -273,6 +275,7 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     bool have_max = false;
     u64 *mwords = nullptr, *malt = nullptr;          // the mirrored words, grouped by their low MIRROR_GROUP_BITS, when dedupe_finish wrote them
     u64* mhist = nullptr;                            // ... and the digit counts of the passes that sort them, when it took those as well
+    int mgroup = MIRROR_GROUP_BITS;                  // ... the low bits they are grouped by (6 more when the blocks told how they split)
     if (dedupe_bit && n) {
         const int pk = pack_bits_for(K);
         DedupeResult r;
@@ -280,8 +283,8 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
         bool done = false;
         // the sample: the leading blocks, about a million keys
         const uint64_t nblocks = 1ull << dedupe_bit, per = n / nblocks + 1;
-        ZK_TRY(dedupe_pass(c, sorted, n, 2 * K, dedupe_bit, pk, other, cap_keys, &r, &n_in, (1u << 20) / per + 4));
-        if (!(r.flags & 1) && (double)r.n_out <= 0.6 * (double)n_in) {
+        if (!presampled) ZK_TRY(dedupe_pass(c, sorted, n, 2 * K, dedupe_bit, pk, other, cap_keys, &r, &n_in, (1u << 20) / per + 4));
+        if (presampled || (!(r.flags & 1) && (double)r.n_out <= 0.6 * (double)n_in)) {
             ZK_TRY(dedupe_pass(c, sorted, n, 2 * K, dedupe_bit, pk, other, cap_keys, &r));
             if (!(r.flags & 1)) {
                 uc = r.n_out;
@@ -293,7 +296,7 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
                 // grouping copy) for free; they go over the keys' buffer (the keys are counted, the words are in the other one).
                 const bool want_m = !(r.flags & 2) && !canonical_only && c->packed_pairs && dedupe_bit == MIRROR_GROUP_BITS &&
                                     2 * K >= MIRROR_GROUP_BITS + 8;
-                ZK_TRY(dedupe_finish(c, r, (u64*)aux, (u32*)(aux + a8), want_m ? sorted : nullptr, K, MIRROR_GROUP_BASES, &mhist));
+                ZK_TRY(dedupe_finish(c, r, (u64*)aux, (u32*)(aux + a8), want_m ? sorted : nullptr, K, MIRROR_GROUP_BASES, &mhist, &mgroup));
                 if (want_m) { mwords = sorted; malt = other; }
                 sorted = (u64*)aux; cnt = (u32*)(aux + a8);
                 in_aux = true;
@@ -411,8 +414,8 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     if (mwords) {
         const int pk = pack_bits_for(K);
         u64* sk = nullptr;
-        if (mhist) ZK_TRY(sort_keys_upper_counted(c, mwords, malt, uc, 2 * K + pk, MIRROR_GROUP_BITS + pk, mhist, &sk));
-        else ZK_TRY(sort_keys_upper(c, mwords, malt, uc, 2 * K + pk, MIRROR_GROUP_BITS + pk, &sk));
+        if (mhist) ZK_TRY(sort_keys_upper_counted(c, mwords, malt, uc, 2 * K + pk, mgroup + pk, mhist, &sk));
+        else ZK_TRY(sort_keys_upper(c, mwords, malt, uc, 2 * K + pk, mgroup + pk, &sk));
         return union_sum_packed_b(c, sorted, cnt, uc, sk, uc, pk, out_k, out_c, cap, n_out);
     }
     const uint64_t a8 = (8 * uc + 255) & ~255ull, a4 = (4 * uc + 255) & ~255ull;

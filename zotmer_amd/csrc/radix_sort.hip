@@ -972,6 +972,7 @@ struct DedupeArgs {
     u32* n_big;
     u32 big_cap;
     u32 chunks;
+    u32* sub;           // or null: [chunks][64] entries of block v whose tag starts with the 6 bits j (the mirror sort groups by them)
 };
 
 // cuts[v] = first index whose key >> tag_bits is >= v, v = 0 .. blocks
@@ -1023,6 +1024,7 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
     if (tid == 0) sm.ticket = atomicAdd(a.counter, 1u);          // the block after this one: read after the next barrier
     if (hi <= lo) {
         if (tid == 0) a.nwords[chunk] = 0;
+        if (a.sub && tid < 64) a.sub[(u64)chunk * 64 + tid] = 0;
         __syncthreads();
         st.chunk = (u32)__builtin_amdgcn_readfirstlane((int)sm.ticket);
         st.lo = st.hi = 0;
@@ -1131,6 +1133,7 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
     __syncthreads();
     const u32 total = sm.bbase[NB];
     if (tid == 0) a.nwords[chunk] = total;
+    if (a.sub && tid < 64) a.sub[(u64)chunk * 64 + tid] = sm.bbase[4 * tid + 4] - sm.bbase[4 * tid];          // four top bytes = one 6-bit start
 #pragma unroll
     for (int j = 0; j < SPT; j++) {
         if (ec[j]) {
@@ -1192,7 +1195,7 @@ struct MirrorHist { int passes; int shift[4]; int bits[4]; u64* raw; };         
 __global__ __launch_bounds__(256) void dedupe_unpack_kernel(const u64* __restrict__ in, const u64* __restrict__ cuts, const u64* __restrict__ incl,
                                                             const u64* __restrict__ nwords, u32 chunks, int pack, u64* __restrict__ out_k,
                                                             u32* __restrict__ out_c, u64* __restrict__ out_m, const u64* __restrict__ minc,
-                                                            int K, int gbases, MirrorHist mh) {
+                                                            int K, int gbases, MirrorHist mh, const u64* __restrict__ place24) {
     __shared__ u32 bins[4 * 512];          // the digit histograms of the mirror sort's passes: it reads every word anyway
     const bool hist = out_m && mh.passes > 0;
     if (hist) {
@@ -1204,14 +1207,18 @@ __global__ __launch_bounds__(256) void dedupe_unpack_kernel(const u64* __restric
         const u64 cnt = nwords[v];
         const u64 dst0 = incl[v] - cnt;
         const u64* src = in + cuts[v];
-        const u64 mdst = out_m ? minc[(u32)revcomp(gbases, (u64)v)] - cnt : 0;
+        const u64 mdst = (out_m && !place24) ? minc[(u32)revcomp(gbases, (u64)v)] - cnt : 0;
+        const int t6 = 2 * K - 2 * gbases - 6;          // where the 6 bits after the block bits sit in a key
         for (u64 i = threadIdx.x; i < cnt; i += blockDim.x) {
             const u64 w = src[i];
             out_k[dst0 + i] = w >> pack;
             out_c[dst0 + i] = (u32)(w & maxc);
             if (out_m) {
                 const u64 mw = (revcomp(K, w >> pack) << pack) | (w & maxc);
-                out_m[mdst + i] = mw;
+                // place24: grouped by 6 more bits -- the block is sorted, so the words that share their next three bases are a
+                // run of it, and place24[v][those 6 bits] + i is the run's place in the group of the mirrored words
+                const u64 at = place24 ? place24[(u64)v * 64 + ((u32)(w >> (pack + t6)) & 63u)] + i : mdst + i;
+                out_m[at] = mw;
                 if (hist) {
 #pragma unroll
                     for (int p = 0; p < 4; p++)
@@ -1225,6 +1232,25 @@ __global__ __launch_bounds__(256) void dedupe_unpack_kernel(const u64* __restric
         for (int q = threadIdx.x; q < mh.passes * 512; q += blockDim.x)
             if (bins[q]) atomicAdd(&mh.raw[q], (u64)bins[q]);
     }
+}
+
+// msz24[g] = words of the run (block v, 6-bit start j) whose mirror image is group g = rc3(j) << (2 gbases) | rc(v)
+__global__ void dedupe_mirror_sizes24_kernel(const u32* __restrict__ sub, u32 chunks, int gbases, u64* __restrict__ msz) {
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (u64)chunks * 64) return;
+    const u32 v = (u32)revcomp(gbases, g & ((u64)chunks - 1)), j = (u32)revcomp(3, g >> (2 * gbases));
+    msz[g] = sub[(u64)v * 64 + j];
+}
+// place24[v][j] = (start of group g(v, j) in the mirror list) - (start of the run inside block v): add the word's index in the block
+__global__ void dedupe_mirror_place24_kernel(const u32* __restrict__ sub, const u64* __restrict__ minc24, u32 chunks, int gbases,
+                                             u64* __restrict__ place) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;          // one wavefront per block: lane = j
+    const u32 v = (u32)(t >> 6), j = (u32)(t & 63);
+    if (v >= chunks) return;
+    const u32 x = sub[(u64)v * 64 + j];
+    const u32 before = wave_incl_scan_u32(x) - x;
+    const u64 g = ((u64)revcomp(3, (u64)j) << (2 * gbases)) | revcomp(gbases, (u64)v);
+    place[(u64)v * 64 + j] = minc24[g] - x - before;
 }
 
 // msz[g] = words of the block whose mirror image is group g
@@ -2014,6 +2040,10 @@ int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int
     a.counter = (u32*)(c->d_scalars + 29);
     a.n_big = (u32*)(c->d_scalars + 30);
     a.big = big; a.big_cap = big_cap;
+    // the mirror sort can group by 6 more bits if the blocks say how their entries split on them: 64 counts per block, when the
+    // workspace has the room (and the finer grouping's tables after it: dedupe_finish)
+    if (!max_chunks && a.tag_bits >= 14 && c->arena_size - c->arena_off > 64ull * chunks * (4 + 8 + 8) + (1ull << 20))
+        ZK_TRY(arena_alloc(c, sizeof(u32) * 64 * chunks, (void**)&a.sub));
     ZK_HIP(c, hipMemsetAsync(c->d_scalars + 27, 0, 4 * sizeof(u64), c->stream));
     prof_begin(c, ZK_PROF_RLE, 8 * n);
     const u32 grid = chunks < (uint64_t)c->num_cus ? (u32)chunks : (u32)c->num_cus;
@@ -2031,21 +2061,38 @@ int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int
     r->flags = (uint32_t)c->h_scalars[27];
     r->n_big = (uint32_t)c->h_scalars[30];
     if (r->n_big > big_cap) r->flags |= 1;          // more counts beyond the field than the side list holds: the long way
-    r->cuts = cuts; r->nwords = nwords; r->incl = incl; r->big = big; r->chunks = (uint32_t)chunks; r->pack = pack; r->work = work;
+    r->cuts = cuts; r->nwords = nwords; r->incl = incl; r->big = big; r->chunks = (uint32_t)chunks; r->pack = pack; r->work = work; r->sub = a.sub;
     if (n_in) *n_in = c->h_scalars[31];          // keys covered by the blocks that were counted
     return ZK_OK;
 }
 
 // out_m (or null; K odd or even, 2 * gbases block bits = all 4^gbases blocks counted): the mirrored words, grouped by their low
 // 2 * gbases bits (dedupe_unpack_kernel) -- ready for the passes over the bits above
-int dedupe_finish(zk_ctx* c, const DedupeResult& r, u64* out_k, u32* out_c, u64* out_m, int K, int gbases, u64** mirror_hist) {
+int dedupe_finish(zk_ctx* c, const DedupeResult& r, u64* out_k, u32* out_c, u64* out_m, int K, int gbases, u64** mirror_hist,
+                  int* mirror_group_bits) {
     if (mirror_hist) *mirror_hist = nullptr;
+    int gbits = 2 * gbases;
+    if (mirror_group_bits) *mirror_group_bits = gbits;
     if (r.n_out == 0) return ZK_OK;
-    u64* minc = nullptr;
+    u64 *minc = nullptr, *place24 = nullptr;
+    if (out_m && (1ull << (2 * gbases)) != r.chunks) return fail(c, ZK_EINTERNAL, "dedupe_finish: %u blocks are not 4^%d", r.chunks, gbases);
+    if (out_m && r.sub && mirror_group_bits && 2 * K - gbits - 6 >= 8) {
+        // 6 more group bits: one pass less for the mirror sort (26 bits above the groups instead of 32 at K = 25)
+        const uint64_t runs = 64ull * r.chunks;
+        u64* minc24;
+        ZK_TRY(arena_alloc(c, sizeof(u64) * runs, (void**)&minc24));
+        ZK_TRY(arena_alloc(c, sizeof(u64) * runs, (void**)&place24));
+        hipLaunchKernelGGL(dedupe_mirror_sizes24_kernel, dim3((u32)div_up(runs, 256)), dim3(256), 0, c->stream, r.sub, r.chunks, gbases, minc24);
+        ZK_TRY(scan64_inclusive(c, minc24, runs));
+        hipLaunchKernelGGL(dedupe_mirror_place24_kernel, dim3((u32)div_up(runs, 256)), dim3(256), 0, c->stream, r.sub, minc24, r.chunks, gbases, place24);
+        ZK_HIP(c, hipGetLastError());
+        gbits += 6;
+        *mirror_group_bits = gbits;
+    }
     MirrorHist mh = {};
     if (out_m && mirror_hist && c->sort_variant == 3) {
         // the digit counts of the passes that will sort the mirrored words above their group bits (sort_keys_upper_counted)
-        const PassPlan plan = make_plan(2 * K - 2 * gbases, V3::RBITS, 2 * gbases + r.pack);
+        const PassPlan plan = make_plan(2 * K - gbits, V3::RBITS, gbits + r.pack);
         if (plan.passes <= 4) {
             ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * V3::RADIX, (void**)&mh.raw));
             ZK_HIP(c, hipMemsetAsync(mh.raw, 0, sizeof(u64) * MAX_PASSES * V3::RADIX, c->stream));
@@ -2054,15 +2101,14 @@ int dedupe_finish(zk_ctx* c, const DedupeResult& r, u64* out_k, u32* out_c, u64*
             *mirror_hist = mh.raw;
         }
     }
-    if (out_m) {
-        if ((1ull << (2 * gbases)) != r.chunks) return fail(c, ZK_EINTERNAL, "dedupe_finish: %u blocks are not 4^%d", r.chunks, gbases);
+    if (out_m && !place24) {
         ZK_TRY(arena_alloc(c, sizeof(u64) * r.chunks, (void**)&minc));
         hipLaunchKernelGGL(dedupe_mirror_sizes_kernel, dim3((r.chunks + 255) / 256), dim3(256), 0, c->stream, r.nwords, r.chunks, gbases, minc);
         ZK_TRY(scan64_inclusive(c, minc, r.chunks));
     }
     prof_begin(c, ZK_PROF_SELECT, (out_m ? 28 : 20) * r.n_out);
     hipLaunchKernelGGL(dedupe_unpack_kernel, dim3((u32)c->num_cus * 8), dim3(256), 0, c->stream, r.work, r.cuts, r.incl, r.nwords, r.chunks, r.pack, out_k, out_c,
-                       out_m, minc, K, gbases, mh);
+                       out_m, minc, K, gbases, mh, place24);
     if (r.n_big) hipLaunchKernelGGL(dedupe_big_kernel, dim3((r.n_big + 255) / 256), dim3(256), 0, c->stream, r.big, r.n_big, out_k, (u64)r.n_out, out_c, c->d_err);
     prof_end(c);
     ZK_HIP(c, hipGetLastError());
