@@ -504,7 +504,9 @@ int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, dou
         return fail(c, ZK_EINVAL, "ZK_KMERIZE_CANONICAL_ONLY cannot be combined with ZK_KMERIZE_BOTH or ZK_KMERIZE_SUBSAMPLE");
     const uint64_t cap_keys = both ? 2 * n_bytes : n_bytes;   // one window per stream byte at most
     arena_reset(c);
-    const uint64_t slack = (9 << 20) + cap_keys / 16;          // histograms, merge-path partitions, the mirror group tables (4 MB)
+    // histograms, merge-path partitions, the mirror group tables (4 MB); from 2^29 stream bytes on (block dedupe with 2^18 blocks) the
+    // blocks' tables as well: bounds, sizes, and the 2^24 run places of the mirror grouping (336 MB)
+    const uint64_t slack = (9 << 20) + cap_keys / 16 + (n_bytes >= (1ull << 29) ? (384ull << 20) : 0);
     ZK_TRY(arena_require(c, 16 * cap_keys + slack, 16 * cap_keys + slack));
     u64 *buf_a, *buf_b;
     ZK_TRY(arena_alloc(c, 8 * cap_keys, (void**)&buf_a));

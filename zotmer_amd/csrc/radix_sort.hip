@@ -2042,7 +2042,8 @@ int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int
     a.big = big; a.big_cap = big_cap;
     // the mirror sort can group by 6 more bits if the blocks say how their entries split on them: 64 counts per block, when the
     // workspace has the room (and the finer grouping's tables after it: dedupe_finish)
-    if (!max_chunks && a.tag_bits >= 14 && c->arena_size - c->arena_off > 64ull * chunks * (4 + 8 + 8) + (1ull << 20))
+    // ... leaving what the sorts and the union after it need (their tables are a few bytes per thousand keys)
+    if (!max_chunks && a.tag_bits >= 14 && c->arena_size - c->arena_off > 64ull * chunks * (4 + 8 + 8) + (32ull << 20) + n / 16)
         ZK_TRY(arena_alloc(c, sizeof(u32) * 64 * chunks, (void**)&a.sub));
     ZK_HIP(c, hipMemsetAsync(c->d_scalars + 27, 0, 4 * sizeof(u64), c->stream));
     prof_begin(c, ZK_PROF_RLE, 8 * n);
