@@ -312,8 +312,11 @@ def test_kmerize_early_collapse_paths_agree(ctx, K):
     rng.shuffle(shared)
     # counts beyond the spare bits of a packed (k-mer << s | count) word (K = 25: 14 bits): the packed forms must step aside
     heavy = deep[:1500] + ["A" * 150] * 400 + ["AC" * 75] * 300
+    # one stretch of the key space with more distinct k-mers than an LDS table of the block dedupe holds (8000 one-window reads that
+    # all start with AAAAA) in an input that otherwise repeats its k-mers: that block alone is counted by sorting
+    dense = deep + ["AAAAA" + "".join(rng.choice(list("ACGT"), size=K - 5)) for _ in range(8000)] if K >= 12 else deep
     for name, reads in (("deep", deep), ("flat", flat), ("shared_low_bits", shared + deep[:500]), ("mixed", deep[:2000] + flat[:2000] + shared),
-                        ("heavy_counts", heavy)):
+                        ("heavy_counts", heavy), ("dense_block", dense)):
         want = zo.kmerize(K, reads)
         d = ctx.upload_stream(stream_of(reads))
         try:

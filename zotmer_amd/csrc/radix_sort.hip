@@ -973,6 +973,9 @@ struct DedupeArgs {
     u32 big_cap;
     u32 chunks;
     u32* sub;           // or null: [chunks][64] entries of block v whose tag starts with the 6 bits j (the mirror sort groups by them)
+    u32* bad;           // [bad_cap] blocks whose table filled up: they write nothing here, the host counts them by sorting
+    u32* n_bad;
+    u32 bad_cap;
 };
 
 // cuts[v] = first index whose key >> tag_bits is >= v, v = 0 .. blocks
@@ -1104,10 +1107,19 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
         for (int i = 0; i < ITEMS; i++) key[i] = nk[i];
         if (nside > (u32)S::SIDE_KEEP || base + TILE >= hi) drain();
     }
-    if (bad) { atomicOr(a.flags, 1u); a.flags[1] = chunk; }          // (the second word: one of the blocks it happened in, for diagnosis)
     st.chunk = nchunk; st.lo = nlo; st.hi = nhi;
     if (nhi > nlo) load(nlo, nhi, st.key);          // the next block's first tile travels while this one is sorted and written
-    __syncthreads();
+    if (__syncthreads_or((int)bad)) {
+        // the table filled up (a block with more distinct keys than it holds): the block goes on the list of those the host
+        // counts by sorting; only when that list is full is the whole run given up
+        if (tid == 0) {
+            const u32 at = atomicAdd(a.n_bad, 1u);
+            if (at < a.bad_cap) a.bad[at] = chunk; else atomicOr(a.flags, 1u);
+            a.nwords[chunk] = 0;
+        }
+        if (a.sub && tid < 64) a.sub[(u64)chunk * 64 + tid] = 0;
+        return;
+    }
     // ---- the block's entries, sorted: a counting sort on the tag's top byte, then ranks inside each byte's group ---------
     // thread t takes the entries t, t + BLOCK, ... into registers; the table's memory then takes them back grouped
     E et[SPT];
@@ -2040,30 +2052,57 @@ int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int
     a.counter = (u32*)(c->d_scalars + 29);
     a.n_big = (u32*)(c->d_scalars + 30);
     a.big = big; a.big_cap = big_cap;
+    const u32 bad_cap = 64;
+    ZK_TRY(arena_alloc(c, sizeof(u32) * bad_cap, (void**)&a.bad));
+    a.bad_cap = bad_cap;
+    a.n_bad = (u32*)(c->d_scalars + 31);
     // the mirror sort can group by 6 more bits if the blocks say how their entries split on them: 64 counts per block, when the
     // workspace has the room (and the finer grouping's tables after it: dedupe_finish)
     // ... leaving what the sorts and the union after it need (their tables are a few bytes per thousand keys)
     if (!max_chunks && a.tag_bits >= 14 && c->arena_size - c->arena_off > 64ull * chunks * (4 + 8 + 8) + (32ull << 20) + n / 16)
         ZK_TRY(arena_alloc(c, sizeof(u32) * 64 * chunks, (void**)&a.sub));
-    ZK_HIP(c, hipMemsetAsync(c->d_scalars + 27, 0, 4 * sizeof(u64), c->stream));
+    ZK_HIP(c, hipMemsetAsync(c->d_scalars + 27, 0, 5 * sizeof(u64), c->stream));
     prof_begin(c, ZK_PROF_RLE, 8 * n);
     const u32 grid = chunks < (uint64_t)c->num_cus ? (u32)chunks : (u32)c->num_cus;
     if (a.tag_bits <= 32) hipLaunchKernelGGL(dedupe_kernel<true>, dim3(grid), dim3(1024), 0, c->stream, a);
     else hipLaunchKernelGGL(dedupe_kernel<false>, dim3(grid), dim3(1024), 0, c->stream, a);
     prof_end(c);
     ZK_HIP(c, hipGetLastError());
-    ZK_HIP(c, hipMemcpyAsync(incl, nwords, sizeof(u64) * chunks, hipMemcpyDeviceToDevice, c->stream));
-    ZK_TRY(scan64_inclusive(c, incl, chunks));
-    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, incl + chunks - 1, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 27, c->d_scalars + 27, 4 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 31, cuts + chunks, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 27, c->d_scalars + 27, 5 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 32, cuts + chunks, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     ZK_TRY(check_device_error(c));
-    r->n_out = c->h_scalars[9];
     r->flags = (uint32_t)c->h_scalars[27];
     r->n_big = (uint32_t)c->h_scalars[30];
     if (r->n_big > big_cap) r->flags |= 1;          // more counts beyond the field than the side list holds: the long way
+    const uint32_t n_bad = (uint32_t)c->h_scalars[31];
+    if (n_bad && n_bad <= bad_cap && !(r->flags & 1) && !max_chunks) {
+        // The few blocks whose table filled up (a stretch of the key space with more distinct k-mers than a table holds) are
+        // counted the plain way, one by one: their keys sorted by the bits below the block bits (the block's own place in `work`
+        // is the second buffer), run lengths into words at that place, the block's word count patched in.
+        uint32_t list[64];
+        ZK_HIP(c, hipMemcpy(list, a.bad, sizeof(u32) * n_bad, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n_bad && !(r->flags & 1); i++) {
+            u64 lohi[2];
+            ZK_HIP(c, hipMemcpy(lohi, cuts + list[i], 2 * sizeof(u64), hipMemcpyDeviceToHost));
+            const uint64_t m = lohi[1] - lohi[0];
+            u64* res = nullptr;
+            ZK_TRY(sort_keys(c, const_cast<u64*>(keys) + lohi[0], work + lohi[0], m, a.tag_bits, &res));
+            if (res != keys + lohi[0]) ZK_HIP(c, hipMemcpyAsync(const_cast<u64*>(keys) + lohi[0], res, 8 * m, hipMemcpyDeviceToDevice, c->stream));
+            uint64_t u = 0;
+            bool ovf = false;
+            ZK_TRY(rle(c, keys + lohi[0], m, work + lohi[0], nullptr, m, &u, pack, &ovf));
+            if (ovf) { r->flags |= 1; break; }          // (a count beyond the field in such a block: the long way after all)
+            ZK_HIP(c, hipMemcpy(nwords + list[i], &u, sizeof(u64), hipMemcpyHostToDevice));
+        }
+        a.sub = nullptr;          // the runs of those blocks were not counted: the mirror sort groups by the block bits only
+    } else if (n_bad > bad_cap) r->flags |= 1;
+    ZK_HIP(c, hipMemcpyAsync(incl, nwords, sizeof(u64) * chunks, hipMemcpyDeviceToDevice, c->stream));
+    ZK_TRY(scan64_inclusive(c, incl, chunks));
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, incl + chunks - 1, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    r->n_out = c->h_scalars[9];
     r->cuts = cuts; r->nwords = nwords; r->incl = incl; r->big = big; r->chunks = (uint32_t)chunks; r->pack = pack; r->work = work; r->sub = a.sub;
-    if (n_in) *n_in = c->h_scalars[31];          // keys covered by the blocks that were counted
+    if (n_in) *n_in = c->h_scalars[32];          // keys covered by the blocks that were counted
     return ZK_OK;
 }
 
