@@ -208,9 +208,18 @@ int mirror_expand(zk_ctx* c, const u64* ck, const u32* cc, uint64_t n, int K, u6
     return check_device_error(c);
 }
 
-// The literal paths: every bit sorted, then RLE; canonical keys are mirrored afterwards.
+// One batch of zk_kmerize.  Canonical mode counts the copies of a k-mer BEFORE the sort is finished -- three ways, tried in
+// this order (zk_tune ZK_TUNE_EARLY_COLLAPSE picks one for tests):
+//   (1) block dedupe: LSD passes over the TOP bits until the blocks of equal top bits are small, then an LDS hash table per
+//       block counts the copies and leaves the block sorted (radix_sort.hip::dedupe_kernel) -- two full-size passes on a
+//       50 M-read batch, and the counted list is finished; dedupe_finish also prepares the mirror sort;
+//   (2) collapse_kernel: LSD passes over the low bits until the copies are within a tile of each other, the next digit ranked
+//       tile by tile with the run lengths counted in LDS, words sorted from that bit up;
+//   (3) the form described next: passes over the low bits until the copies are neighbours, a run-length pass, pairs above.
+// Then the strands are rebuilt (mirror_union, or straight from the blocks).  ZK_KMERIZE_BOTH: every bit of both strands
+// sorted, then RLE (the literal path).
 //
-// Early collapse (canonical mode).  Sequencing reads repeat every k-mer `coverage` times, and an LSD sort drags all those
+// Early collapse (3).  Sequencing reads repeat every k-mer `coverage` times, and an LSD sort drags all those
 // copies through every pass.  But after the passes over the low b bits the copies of a k-mer are already NEIGHBOURS as soon
 // as 2^b is well above the number of keys (two distinct k-mers rarely share their low b bits), so the run-length count
 // can be taken THEN: the remaining passes move (k-mer, count) pairs -- one per distinct k-mer instead of one per copy --
