@@ -86,6 +86,7 @@ struct SortArgs {
     // bytes (rec - 1 bases + the separator); a tile takes `rpt` records, a thread one of the `cpr` 16-window chunks of a
     // record, which has `wpr` windows.  Verified by the histogram kernel before it is used (see sort_stream).
     u32 rec, rpt, cpr, wpr;
+    u32 cpr_inv;        // ceil(2^32 / cpr): thread / cpr as a multiply (exact for thread < 2^16)
     // outputs
     u64* kout;
     u32* vout;
@@ -1494,9 +1495,11 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                 // tile position p0 -- 16 * tid for tiles of TILE positions; for record-aligned tiles thread = (record r
                 // of the tile, chunk j of its windows), so that no slot is spent on the K windows per record that
                 // run into the separator.
-                u32 p0 = 16u * (u32)tid, lim = 0xffffu;
+                // (from the opaque thread index and by a multiply: cheap enough to redo per tile, so that p0 and lim are not kept
+                // -- or spilled -- across the tile loop)
+                u32 p0 = 16u * tid_o, lim = 0xffffu;
                 if (a.rec) {
-                    const u32 r = (u32)tid / a.cpr, j = (u32)tid - r * a.cpr;
+                    const u32 r = (u32)(((u64)tid_o * a.cpr_inv) >> 32), j = tid_o - r * a.cpr;
                     p0 = r * a.rec + 16u * j;
                     const int left = (int)a.wpr - 16 * (int)j;              // windows of the record from this chunk on
                     lim = (r < a.rpt) ? ((left >= 16) ? 0xffffu : ((1u << (left > 0 ? left : 0)) - 1u)) : 0u;
@@ -1510,6 +1513,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                 }
                 __syncthreads();      // the image is dead: its space becomes the counters
             }
+            // (Pass 0 has no order to keep, so its ranks could come from a returning LDS add per key instead of the ballots: measured,
+            // 32.7 vs 30.9 ms.)
             // this wave's counters: private to the wave until the scan, so no barrier after zeroing them
             {
                 u32 z = 0;          // made here, not kept: a zero quad held (or spilled) across the tile loop costs four registers
@@ -1565,7 +1570,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                     for (int i = 0; i < ITEMS; i++) nx.key[i] = p[i * 64];
                     nx.live = (1u << ITEMS) - 1u;
                 }
-            }
+            }          // (stream source: its next tile is only 16-32 bytes per thread; asking for it here as well was slower, 31.5 vs 30.8 ms)
             // ---- per digit: scan over the waves, publish the tile's count at once -------------------
             u32 tsum = 0;
 #pragma unroll
@@ -1917,6 +1922,7 @@ struct Sorter {
                     if (rpt >= 16 && (uint64_t)rpt * rec / 16 + 3 <= (uint64_t)PipeSmem<C>::IMG_WORDS &&
                         (double)rpt * (double)W > 1.02 * (double)C::TILE * (double)W / (double)rec) {
                         a.rec = (u32)rec; a.rpt = rpt; a.cpr = cpr; a.wpr = (u32)W;
+                        a.cpr_inv = (u32)(((1ull << 32) + cpr - 1) / cpr);
                     }
                 }
             }
