@@ -333,11 +333,17 @@ __global__ __launch_bounds__(C::BLOCK, PRE ? 8 : 1) void hist_kernel(HistArgs h)
                     if (wg.get(i, x, xb)) {
                         pk += (1u << (8 * (u32)(x & 3))) + (1u << (8 * (u32)(xb & 3)));
                         const u64 kk = (h.src.mode == ZK_KEYS_CANONICAL) ? (x < xb ? x : xb) : x;
+                        if (h.plan.passes == 2) {
+                            // the usual plan (two passes over the top bits, then the block dedupe): no test per possible pass
+                            atomicAdd(&bins[(u32)(kk >> h.plan.shift[0]) & ((1u << h.plan.bits[0]) - 1u)], 1u);
+                            atomicAdd(&bins[C::RADIX + ((u32)(kk >> h.plan.shift[1]) & ((1u << h.plan.bits[1]) - 1u))], 1u);
+                        } else {
 #pragma unroll
-                        for (int p = 0; p < MAX_PASSES; p++) {
-                            if (p < h.plan.passes) {
-                                const u32 d = (u32)(kk >> h.plan.shift[p]) & ((1u << h.plan.bits[p]) - 1u);
-                                atomicAdd(&bins[p * C::RADIX + d], 1u);
+                            for (int p = 0; p < MAX_PASSES; p++) {
+                                if (p < h.plan.passes) {
+                                    const u32 d = (u32)(kk >> h.plan.shift[p]) & ((1u << h.plan.bits[p]) - 1u);
+                                    atomicAdd(&bins[p * C::RADIX + d], 1u);
+                                }
                             }
                         }
                         if (h.sample && (kk >> h.sample_shift) == h.sample_value) {
