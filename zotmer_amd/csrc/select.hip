@@ -891,11 +891,24 @@ __global__ __launch_bounds__(256) void count_hist_kernel(const CT* __restrict__ 
     __syncthreads();
     // Counts are few distinct values (most k-mers of a sequencing run occur once, the rest near the coverage), and 64
     // LDS atomics on one word take 64 turns: peel the two commonest values of the wave, their first lane adds the lot.
-    const u64 step = (u64)gridDim.x * 256;
-    for (u64 i0 = (u64)blockIdx.x * 256; i0 < n; i0 += step) {      // uniform trip count: every lane reaches the ballots
-        const u64 i = i0 + threadIdx.x;
-        bool act = i < n;
-        const u64 v = act ? (u64)counts[i] : 0ull;
+    // The commonest value of all -- 1: the k-mers that a read error made -- never reaches LDS: a register per thread, one add per
+    // wave at the end.  Four rows of loads are in flight at a time.
+    constexpr int ROWS = 4;
+    u32 ones = 0;
+    const u64 step = (u64)gridDim.x * 256 * ROWS;
+    for (u64 i0 = (u64)blockIdx.x * 256 * ROWS; i0 < n; i0 += step) {      // uniform trip count: every lane reaches the ballots
+      u64 vv[ROWS];
+#pragma unroll
+      for (int q = 0; q < ROWS; q++) {
+          const u64 i = i0 + (u64)q * 256 + threadIdx.x;
+          vv[q] = i < n ? (u64)counts[i] : 1ull << 63;          // (past the end: a value nobody counts)
+      }
+#pragma unroll
+      for (int q = 0; q < ROWS; q++) {
+        const u64 v = vv[q];
+        ones += v == 1 ? 1u : 0u;
+        bool act = v != 1 && v != (1ull << 63);
+        if (!__any((int)act)) continue;
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             const u64 m = __ballot(act && v < HIST_DENSE);
@@ -914,7 +927,10 @@ __global__ __launch_bounds__(256) void count_hist_kernel(const CT* __restrict__ 
                 if (slot < big_cap) big[slot] = v;
             }
         }
+      }
     }
+    ones = wave_sum_u32(ones);
+    if ((threadIdx.x & 63) == 0 && ones) atomicAdd(&bins[1], ones);
     __syncthreads();
     for (int i = threadIdx.x; i < HIST_DENSE; i += 256)
         if (bins[i]) atomicAdd(&dense[i], (u64)bins[i]);
