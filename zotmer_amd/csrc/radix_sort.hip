@@ -1228,20 +1228,32 @@ __global__ __launch_bounds__(256) void dedupe_unpack_kernel(const u64* __restric
         const u64* src = in + cuts[v];
         const u64 mdst = (out_m && !place24) ? minc[(u32)revcomp(gbases, (u64)v)] - cnt : 0;
         const int t6 = 2 * K - 2 * gbases - 6;          // where the 6 bits after the block bits sit in a key
-        for (u64 i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const u64 w = src[i];
-            out_k[dst0 + i] = w >> pack;
-            out_c[dst0 + i] = (u32)(w & maxc);
-            if (out_m) {
-                const u64 mw = (revcomp(K, w >> pack) << pack) | (w & maxc);
-                // place24: grouped by 6 more bits -- the block is sorted, so the words that share their next three bases are a
-                // run of it, and place24[v][those 6 bits] + i is the run's place in the group of the mirrored words
-                const u64 at = place24 ? place24[(u64)v * 64 + ((u32)(w >> (pack + t6)) & 63u)] + i : mdst + i;
-                out_m[at] = mw;
-                if (hist) {
+        // four words of a thread in flight at a time (a block is ~3 K words: twelve rounds of one load each otherwise)
+        for (u64 i0 = threadIdx.x; i0 < cnt; i0 += 4ull * blockDim.x) {
+            u64 w4[4];
 #pragma unroll
-                    for (int p = 0; p < 4; p++)
-                        if (p < mh.passes) atomicAdd(&bins[p * 512 + ((u32)(mw >> mh.shift[p]) & ((1u << mh.bits[p]) - 1u))], 1u);
+            for (int q = 0; q < 4; q++) {
+                const u64 i = i0 + (u64)q * blockDim.x;
+                w4[q] = i < cnt ? src[i] : 0;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u64 i = i0 + (u64)q * blockDim.x;
+                if (i >= cnt) break;
+                const u64 w = w4[q];
+                out_k[dst0 + i] = w >> pack;
+                out_c[dst0 + i] = (u32)(w & maxc);
+                if (out_m) {
+                    const u64 mw = (revcomp(K, w >> pack) << pack) | (w & maxc);
+                    // place24: grouped by 6 more bits -- the block is sorted, so the words that share their next three bases are
+                    // a run of it, and place24[v][those 6 bits] + i is the run's place in the group of the mirrored words
+                    const u64 at = place24 ? place24[(u64)v * 64 + ((u32)(w >> (pack + t6)) & 63u)] + i : mdst + i;
+                    out_m[at] = mw;
+                    if (hist) {
+#pragma unroll
+                        for (int p = 0; p < 4; p++)
+                            if (p < mh.passes) atomicAdd(&bins[p * 512 + ((u32)(mw >> mh.shift[p]) & ((1u << mh.bits[p]) - 1u))], 1u);
+                    }
                 }
             }
         }
