@@ -82,12 +82,27 @@ __global__ __launch_bounds__(1024) void mirror_scan_kernel(u64* __restrict__ siz
 __global__ void mirror_copy_kernel(const u64* __restrict__ c, const u32* __restrict__ n, u64 m, int K, const u64* __restrict__ start,
                                    const u64* __restrict__ dest, u64* __restrict__ r, u32* __restrict__ v, int pack) {
     const int sh = 2 * K - MIRROR_GROUP_BITS;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (u64)gridDim.x * blockDim.x) {
-        const u64 x = c[i];
-        const u32 g = (u32)(x >> sh);
-        const u64 pos = dest[(u32)revcomp(MIRROR_GROUP_BASES, (u64)g)] + (i - start[g]);      // dest is indexed by v = rc9(g)
-        if (pack) r[pos] = (revcomp(K, x) << pack) | (u64)n[i];
-        else { r[pos] = revcomp(K, x); v[pos] = n[i]; }
+    // four entries of a thread in flight at a time
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x; i0 < m; i0 += 4 * stride) {
+        u64 x4[4];
+        u32 n4[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u64 i = i0 + q * stride;
+            x4[q] = i < m ? c[i] : 0;
+            n4[q] = i < m ? n[i] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u64 i = i0 + q * stride;
+            if (i >= m) break;
+            const u64 x = x4[q];
+            const u32 g = (u32)(x >> sh);
+            const u64 pos = dest[(u32)revcomp(MIRROR_GROUP_BASES, (u64)g)] + (i - start[g]);      // dest is indexed by v = rc9(g)
+            if (pack) r[pos] = (revcomp(K, x) << pack) | (u64)n4[q];
+            else { r[pos] = revcomp(K, x); v[pos] = n4[q]; }
+        }
     }
 }
 
