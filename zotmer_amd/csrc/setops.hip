@@ -19,7 +19,7 @@
 
 namespace zk {
 
-constexpr int MRG_BLOCK = 256;
+constexpr int MRG_BLOCK = 512;
 constexpr int MRG_ITEMS = 8;
 constexpr int MRG_TILE = MRG_BLOCK * MRG_ITEMS;
 constexpr int MRG_NW = MRG_BLOCK / 64;
