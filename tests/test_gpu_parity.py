@@ -398,6 +398,59 @@ def test_kmerize_record_aligned_tiles_and_fallbacks(ctx, case):
     assert list(st.acgt) == want["acgt"]
 
 
+@pytest.mark.parametrize("shape", ["u150", "var_100_150", "u100_k31", "fasta_like_long", "lower_and_u", "poly_a", "u150_k9", "u150_k32"])
+def test_kmerize_stream_ranges_pass(ctx, shape):
+    """The first sort pass over static stream ranges (stream_pass.hip): one workgroup walks a range tile by tile, keeps what is
+    left of a digit (fewer keys than a store unit) in LDS for the next tile, and writes whole units only.  With 3, 7 and the
+    default number of ranges (a range of many tiles, of few, of at most one), every unit size, with and without the look before
+    the sort, the arrays must be the oracle's; and the look-back pipeline (stream_pass = 0) must still agree."""
+    rng = np.random.default_rng(sum(map(ord, shape)))
+
+    def rnd(n, p_n=0.001, alphabet="ACGT"):
+        a = rng.choice(list(alphabet), size=n)
+        a[rng.random(n) < p_n] = "N"
+        return "".join(a)
+    K = 25
+    genome = rnd(30000, 0.0)
+
+    def sampled(L):
+        p = int(rng.integers(0, len(genome) - L))
+        return genome[p:p + L]
+    if shape == "u150":
+        reads = [sampled(150) for _ in range(30000)]                        # ~470 record tiles, repeats its k-mers
+    elif shape == "var_100_150":
+        reads = [sampled(int(rng.integers(100, 151))) for _ in range(30000)]    # never uniform: tiles of positions
+    elif shape == "u100_k31":
+        K, reads = 31, [sampled(100) for _ in range(20000)]
+    elif shape == "fasta_like_long":
+        reads = [rnd(int(rng.integers(5000, 60000)), 0.0005) for _ in range(40)]   # records longer than a tile
+    elif shape == "lower_and_u":
+        reads = [rnd(150, 0.002, "ACGTacgtUu") for _ in range(20000)]
+    elif shape == "poly_a":
+        reads = ["A" * 150] * 6000 + [sampled(150) for _ in range(6000)] + ["T" * 150] * 3000      # one digit takes whole tiles
+    elif shape == "u150_k9":
+        K, reads = 9, [sampled(150) for _ in range(8000)]                    # 18 key bits: two passes of 9, nothing above bit 32
+    else:
+        K, reads = 32, [sampled(150) for _ in range(8000)]
+    want = zo.kmerize(K, reads)
+    d = ctx.upload_stream(stream_of(reads))
+    try:
+        for ranges in (3, 7, 0):
+            for variant in (1, 2, 3, 0):
+                for collapse in ((1, 0) if variant == 1 else (1,)):
+                    ctx.tune(stream_pass=variant, stream_ranges=ranges, early_collapse=collapse)
+                    k, c, st = ctx.kmerize(d, K)
+                    assert np.array_equal(k.to_host(), want["kmers"]), (shape, ranges, variant, collapse)
+                    assert np.array_equal(c.to_host(), want["counts"]), (shape, ranges, variant, collapse)
+                    assert list(st.acgt) == want["acgt"] and st.n_unique == len(want["kmers"]), (shape, ranges, variant, collapse)
+        # both strands sorted literally: pass 0 emits x and rc(x) -- the pipeline's path, whatever the knob says
+        ctx.tune(stream_pass=1, stream_ranges=0, early_collapse=1)
+        k, c, st = ctx.kmerize(d, K, native.KMERIZE_BOTH)
+        assert np.array_equal(k.to_host(), want["kmers"]) and np.array_equal(c.to_host(), want["counts"])
+    finally:
+        ctx.tune(stream_pass=1, stream_ranges=0, early_collapse=1)
+
+
 @pytest.mark.parametrize("K", [4, 24, 32])
 def test_kmerize_even_K_palindromes_vs_oracle(ctx, K):
     # even K: x == rc(x) exists; the mirrored path must count such a window twice, like two emissions

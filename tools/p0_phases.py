@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Diagnostic: where wave 0 of a stream_pass0_kernel workgroup spends a tile (in-kernel s_memtime, 100 MHz ticks), and the
+HIP-event times of the histogram and the pass.  usage: p0_phases.py [reads] [stream_pass variant] [K]"""
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from zotmer_amd import native, synth
+
+reads = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20_000_000
+variant = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 25
+cfg = synth.CONFIGS["config2"]
+ctx = native.Context(0)
+ctx.tune(stream_pass=variant)
+d = ctx.synth_reads(synth.DEFAULT_SEED, 0, reads, cfg["L"], genome=cfg["genome"], sub_thr=synth.frac32(cfg["sub"]), n_thr=synth.frac32(cfg["n"]))
+ctx.kmerize(d, K)
+dbg = ctx.empty(4096 * 16, np.uint64)
+ctx._check(ctx.lib.zk_debug_buffer(ctx.h, dbg.ptr))
+ctx.profile(True)
+ctx.kmerize(d, K)
+ctx.sync()
+prof = ctx.profile_read()
+ctx.profile(False)
+ctx._check(ctx.lib.zk_debug_buffer(ctx.h, None))
+raw = dbg.to_host().reshape(4096, 16).astype(np.float64)
+raw = raw[raw[:, 8] > 0]
+names = ["keys + rank", "barrier", "scan (2 barriers)", "park", "barrier", "next image (+ wait for bytes)", "stores issued", "barrier"]
+tiles = raw[:, 8].sum()
+per = raw[:, :8].sum(axis=0) / tiles * 10.0          # ns per tile
+out = {"reads": reads, "variant": variant, "K": K, "ranges": int(len(raw)), "tiles_per_range": float(raw[:, 8].mean()),
+       "ns_per_tile": {n: round(float(v), 1) for n, v in zip(names, per)}, "ns_per_tile_total": round(float(per.sum()), 1),
+       "hist_stream_ms": prof.get("hist_stream", {}).get("ms"), "pass_stream_ms": prof.get("pass_stream", {}).get("ms")}
+print(json.dumps(out))

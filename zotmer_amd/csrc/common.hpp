@@ -25,6 +25,7 @@ typedef unsigned char u8;
 #define ZK_DERR_CAPACITY 4u       // an output did not fit the caller's buffer
 #define ZK_DERR_RANGE 8u          // codec64: a value (or k-mer delta) >= 2^60 has no code
 #define ZK_DERR_BAD_TAG 16u       // codec64: a word carries a tag the format does not define
+#define ZK_DERR_MISMATCH 32u      // stream_pass.hip: the pass did not write what the histogram had counted for it
 
 namespace zk {
 

@@ -139,6 +139,7 @@ int check_device_error(zk_ctx* c) {
     if (e & ZK_DERR_BAD_TAG) return fail(c, ZK_ERANGE, "corrupt codec64 stream (unknown tag)");
     if (e & ZK_DERR_CAPACITY) return fail(c, ZK_ENOSPC, "output does not fit the capacity given");
     if (e & ZK_DERR_COUNT_OVERFLOW) return fail(c, ZK_EOVERFLOW, "a k-mer count does not fit the count type");
+    if (e & ZK_DERR_MISMATCH) return fail(c, ZK_EINTERNAL, "the first sort pass and the histogram before it disagree on the keys of a stream range");
     return fail(c, ZK_EINTERNAL, "device error word 0x%x", e);
 }
 
@@ -311,6 +312,8 @@ int zk_tune(zk_ctx* c, int what, int value) {
     if (what == ZK_TUNE_PACKED_PAIRS) { c->packed_pairs = value ? 1 : 0; return ZK_OK; }
     if (what == ZK_TUNE_EARLY_COLLAPSE) { c->early_collapse = value < 0 ? 0 : (value > 3 ? 3 : value); return ZK_OK; }
     if (what == ZK_TUNE_COMM_CHUNK) { c->comm_chunk_bytes = value > 0 ? (uint64_t)value : 0; return ZK_OK; }
+    if (what == ZK_TUNE_STREAM_PASS) { c->stream_pass = value < 0 ? 0 : value; return ZK_OK; }
+    if (what == ZK_TUNE_STREAM_RANGES) { c->stream_ranges = value < 0 ? 0 : (value > 4096 ? 4096 : value); return ZK_OK; }
     if (what == ZK_TUNE_XCD_GROUP) {
         if (value < 0 || value > 32 || (value & (value - 1))) return fail(c, ZK_EINVAL, "xcd group must be 0 or a power of two <= 32");
         c->xcd_group = value;

@@ -26,6 +26,9 @@ struct zk_ctx {
                                // 2 = a run-length pass of its own once the copies are neighbours (the round's first form), 0 = off
     int side_div = 8;          // ... side list capacity = n / side_div (tests shrink it to force the fallback)
     int pairs_variant = 2;     // ... for (key, u32) pairs
+    int stream_pass = 1;       // the first sort pass (from the base stream): 1 = static ranges, whole 64-byte units written from LDS
+                               // (stream_pass.hip; 2, 3 = its other unit sizes, for measurements), 0 = the look-back pipeline
+    int stream_ranges = 0;     // ... ranges the stream is cut into (0 = one per CU; tests use a few so that a range has many tiles)
 
     // workspace arena: a bump allocator reset at the start of every API call
     char* arena = nullptr;
@@ -110,6 +113,12 @@ static inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; 
 
 // ---- launchers implemented in the kernel files (all asynchronous on c->stream) -------------
 // radix_sort.hip
+constexpr int MAX_PASSES = 8;
+struct PassPlan {          // the digits of an LSD sort: pass p takes bits [shift[p], shift[p] + bits[p])
+    int passes;
+    int shift[MAX_PASSES];
+    int bits[MAX_PASSES];
+};
 int sort_workspace_bytes(uint64_t n, bool pairs, uint64_t* bytes);
 int sort_keys(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** result);
 int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, u64** rk, u32** rv);
@@ -143,6 +152,13 @@ int collapse_pass(zk_ctx* c, const u64* keys, uint64_t n, int shift, int bits, i
                   uint64_t max_tiles = 0);
 int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,
                 uint64_t acgt[4], u64** result);
+// stream_pass.hip: histogram + first pass over static stream ranges
+struct StreamRows { u32* rows = nullptr; u64* offs = nullptr; u32 ranges = 0, radix = 0; };
+int stream_hist(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, const PassPlan& plan, u64* ghist, u32 gstride,
+                u64* d_acgt, u64* d_n, u64* rec_info, u64* sample, u32 sample_cap, int sample_shift, u64 sample_value, u32* sample_n,
+                StreamRows* out);
+int stream_pass0(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, int shift, int bits, const u64* ghist0, const StreamRows& rows,
+                 uint64_t first_nl, bool uniform, u64* kout, uint64_t n, int variant);
 // select.hip
 int trim(zk_ctx* c, const u64* keys, const void* cnts, int cbits, uint64_t n, u64 lo, u64 hi, u64* ok, void* oc,
          uint64_t cap, uint64_t* n_out);

@@ -27,7 +27,6 @@
 
 namespace zk {
 
-constexpr int MAX_PASSES = 8;
 constexpr int MAX_RADIX = 1024;
 
 enum { SRC_ARRAY = 0, SRC_STREAM = 1 };
@@ -48,12 +47,6 @@ struct Cfg {
     static_assert(ITEMS % 2 == 0 && 2 * ITEMS < 256, "ITEMS");
     static_assert(64 * ITEMS < 65536, "per-wave ranks are 16-bit");
     static_assert(RADIX <= MAX_RADIX && RBITS * MAX_PASSES >= 64, "RBITS");
-};
-
-struct PassPlan {
-    int passes;
-    int shift[MAX_PASSES];
-    int bits[MAX_PASSES];
 };
 
 static PassPlan make_plan(int key_bits, int rbits, int lo = 0) {
@@ -1901,8 +1894,22 @@ struct Sorter {
         // the look before the sort (StreamSample): the set-aside keys go to the second sort buffer, which is idle until pass 1
         const u32 sample_cap = 1u << 20;
         const bool sampling = src.sample && cap >= 4ull * sample_cap && src.mode == ZK_KEYS_CANONICAL;
-        ZK_TRY(launch_hist<SRC_STREAM>(c, a, plan, ghist, d_acgt, d_n, sampling ? buf_b : nullptr, sample_cap,
-                                       sampling ? src.sample->shift : 0, sampling ? src.sample->value : 0));
+        // stream_pass.hip: the pass over static stream ranges needs the digit counts of pass 0 per range, from its own histogram kernel
+        const bool ranged = c->stream_pass && src.mode != ZK_KEYS_BOTH;
+        StreamRows srows;
+        if (ranged) {
+            u64* rec_info = c->d_scalars + 20;
+            ZK_HIP(c, hipMemsetAsync(rec_info, 0, 4 * sizeof(u64), c->stream));          // [20..22] the records, [23] the sample counter
+            hipLaunchKernelGGL(first_newline_kernel, dim3(1), dim3(256), 0, c->stream, src.stream, (u64)src.n_bytes, rec_info);
+            ZK_TRY(stream_hist(c, src.stream, src.n_bytes, src.K, src.mode, plan, ghist, (u32)C::RADIX, d_acgt, d_n, rec_info,
+                               sampling ? buf_b : nullptr, sample_cap, sampling ? src.sample->shift : 0, sampling ? src.sample->value : 0,
+                               (u32*)(c->d_scalars + 23), &srows));
+            hipLaunchKernelGGL(hist_scan_kernel, dim3(1), dim3(256), 0, c->stream, ghist, plan.passes, (int)C::RADIX, d_n);
+            ZK_HIP(c, hipGetLastError());
+        } else {
+            ZK_TRY(launch_hist<SRC_STREAM>(c, a, plan, ghist, d_acgt, d_n, sampling ? buf_b : nullptr, sample_cap,
+                                           sampling ? src.sample->shift : 0, sampling ? src.sample->value : 0));
+        }
         // the number of live keys decides the grids of the array passes: one small readback
         ZK_HIP(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(u64) * 24, hipMemcpyDeviceToHost, c->stream));
         ZK_HIP(c, hipStreamSynchronize(c->stream));
@@ -1926,6 +1933,12 @@ struct Sorter {
         }
         a.kout = buf_a; a.shift = plan.shift[0]; a.bits = plan.bits[0]; a.ghist = ghist;
         a.n = n;
+        if (ranged) {
+            const uint64_t first_nl = c->h_scalars[20], nl = c->h_scalars[21], bad = c->h_scalars[22];
+            const bool uniform = first_nl < 0x7fffffffull && src.n_bytes % (first_nl + 1) == 0 && bad == 0 && nl == src.n_bytes / (first_nl + 1);
+            ZK_TRY(stream_pass0(c, src.stream, src.n_bytes, src.K, src.mode, plan.shift[0], plan.bits[0], ghist, srows, first_nl, uniform, buf_a, n,
+                                c->stream_pass));
+        } else
         if constexpr (C::PIPE && C::ITEMS == 16 && PipeSmem<C>::IMG_FITS && C::BLOCK <= 512) {
             // Uniform records (checked by the histogram kernel: the only newlines are one every `rec` bytes): tiles follow
             // the records, so that no key slot is spent on the windows that run into a separator (17 % of the

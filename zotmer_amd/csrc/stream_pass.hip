@@ -1,0 +1,613 @@
+// stream_pass.hip -- the histogram and the first pass of the k-mer sort, as a count / scan / scatter pass over STATIC ranges.
+//
+// Replaces the first pass of misc.radix_sort (zotmer/library/misc.py:400-424) over the k-mers that basics.kmersList
+// (zotmer/library/basics.py:303-347) makes of the reads (commands/kmerize.py:490-493, 412-417).
+//
+// Why not the look-back pipeline of radix_sort.hip for this pass: what bounds a scatter pass on MI355X is who writes which
+// 128-byte line (tools/scatter_bench2.hip, profiles/r03/scatter_patterns.json).  6.2 G keys into 512 streams take 10-12 ms when
+// every 64- or 128-byte unit is written whole by ONE wave instruction, and 20-25 ms when the units are cut by run borders -- which
+// is what a tile-by-tile pass does: tile t's 16 keys of a digit land wherever the counts of the tiles before it say.  The first
+// pass has no order to keep (its input is the read stream), so here
+//   * the stream is cut into one contiguous RANGE per workgroup (one workgroup per CU);
+//   * the histogram kernel, which reads the stream anyway, also counts the digits of this pass PER RANGE (rows);
+//   * a scan gives every (range, digit) its own contiguous piece of the output;
+//   * the pass kernel walks its range tile by tile, parks each tile grouped by digit in LDS, and writes only WHOLE units of G
+//     keys (G * 8 bytes, aligned in the output); what is left of a digit (fewer than G keys) waits in LDS for the next tile.
+// No look-back, no scanner workgroups, no status words, no atomics outside LDS.
+//
+// The same file holds the leaner histogram kernel: bytes -> 2-bit codes four at a time (SWAR), the canonical strand decided on
+// the words that hold the digits, acgt from population counts instead of per-window adds.
+#include "internal.hpp"
+#include "encode_tile.hpp"
+
+#include <type_traits>
+
+namespace zk {
+
+constexpr int P0_BLOCK = 1024, P0_NW = 8, P0_TILE = P0_BLOCK * P0_NW, P0_IMG_WORDS = 640;
+constexpr int SH_BLOCK = 512, SH_NW = 16, SH_TILE = SH_BLOCK * SH_NW;          // the histogram kernel's tiles: positions
+
+// How the stream is cut.  Decided from the position of the stream's first newline alone (the histogram kernel runs before
+// anybody knows whether the records are uniform), by the same function on the device and on the host.
+struct StreamTiling {
+    u32 rec;              // bytes per record (bases + separator) if the stream might consist of uniform records, else 0
+    u32 rpt, cpr, wpr;    // records per tile, threads per record, windows per record
+    u32 cpr_inv;          // ceil(2^32 / cpr)
+    u32 tile_bytes;       // stream bytes per tile of the pass (rpt * rec, or P0_TILE positions)
+    u32 ranges;
+    u64 range_bytes;      // stream bytes per range: a whole number of tiles, a multiple of 16
+};
+
+__host__ __device__ inline StreamTiling make_tiling(u64 n_bytes, u64 first_nl, int K, u32 ranges) {
+    StreamTiling t = {};
+    t.ranges = ranges ? ranges : 1;
+    t.tile_bytes = P0_TILE;
+    if (first_nl < 0x7fffffffull) {
+        const u64 rec = first_nl + 1;
+        const long long W = (long long)first_nl - K + 1;
+        if (rec >= 16 && W >= 1 && n_bytes % rec == 0) {
+            const u32 cpr = (u32)((W + P0_NW - 1) / P0_NW);
+            u32 rpt = cpr <= (u32)P0_BLOCK ? ((u32)P0_BLOCK / cpr) / 16 * 16 : 0;
+            const u32 fit = (u32)((16ull * (P0_IMG_WORDS - 3)) / rec) / 16 * 16;
+            if (rpt > fit) rpt = fit;
+            // tiles that follow the records spend no key slot on the windows that run into a separator: worth it when such a
+            // tile covers more of the stream than a tile of positions
+            if (rpt >= 16 && (u64)rpt * rec * 50 > (u64)P0_TILE * 51) {
+                t.rec = (u32)rec; t.rpt = rpt; t.cpr = cpr; t.wpr = (u32)W;
+                t.cpr_inv = (u32)(((1ull << 32) + cpr - 1) / cpr);
+                t.tile_bytes = rpt * (u32)rec;
+            }
+        }
+    }
+    const u64 tiles = (n_bytes + t.tile_bytes - 1) / t.tile_bytes;
+    const u64 tpr = (tiles + t.ranges - 1) / t.ranges;
+    t.range_bytes = (tpr ? tpr : 1) * (u64)t.tile_bytes;
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------
+// bytes -> 2-bit codes and validity, four bytes per operation
+// ---------------------------------------------------------------------------------------
+// 16 stream bytes -> codes (2 bits per base, first base in the top bits) and validity (16 bits, first base in bit 15); the same
+// function of the bytes as encode_words16 (A a C c G g T t U u are bases, zotmer/library/basics.py:42-46).
+__device__ __forceinline__ void encode_swar16(const uint4 q, u32& codes, u32& vmask) {
+    const u32 w[4] = {q.x, q.y, q.z, q.w};
+    u32 cc = 0, vv = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        // codes: bits 2..1 of the byte, A0 C1 G3 T2 -> A0 C1 G2 T3
+        const u32 t = (w[i] >> 1) & 0x03030303u;
+        const u32 code = t ^ ((t >> 1) & 0x01010101u);
+        const u32 g = (code | (code >> 6) | (code >> 12) | (code >> 18)) & 0xffu;          // byte j's code at bits 2j
+        cc |= g << (8 * i);
+        // validity: x = byte | 0x20 is one of 0x61 0x63 0x67 0x74 0x75:
+        //   ~b7 & b6 & ~b3 & (b4 ? (b2 & ~b1) : (b0 & ~(b2 & ~b1)))
+        const u32 x = w[i] | 0x20202020u;
+        const u32 t1 = (x >> 2) & ~(x >> 1);
+        const u32 b4 = x >> 4;
+        const u32 inner = (b4 & t1) | (~b4 & x & ~t1);
+        const u32 ok = ~(x >> 7) & (x >> 6) & ~(x >> 3) & inner & 0x01010101u;
+        const u32 n = (ok | (ok >> 7) | (ok >> 14) | (ok >> 21)) & 0xfu;                   // byte j's bit at bit j
+        vv |= n << (4 * i);
+    }
+    // first base low -> first base high
+    const u32 y = __brev(cc);
+    codes = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+    vmask = __brev(vv) >> 16;
+}
+
+// (a : b) >> t, 0 <= t < 128 (per lane): the low three 32-bit words
+__device__ __forceinline__ void shr128(u64 a, u64 b, u32 t, u32& w0, u32& w1, u32& w2) {
+    const u32 s = t & 63u;
+    const u64 lo_small = s ? ((b >> s) | (a << (64 - s))) : b;          // t < 64
+    const u64 hi_small = a >> s;
+    const bool big = t >= 64;
+    const u64 lo = big ? hi_small : lo_small;
+    const u64 hi = big ? 0ull : hi_small;
+    w0 = (u32)lo; w1 = (u32)(lo >> 32); w2 = (u32)hi;
+}
+
+// The NW windows that start at string position s .. s + NW - 1 of the 64 bases in (a : b), as three-word strings from which every
+// window is two funnel shifts by a CONSTANT: forward  x_i = (S' >> 2 (NW - 1 - i)) & mask,  reverse complement  xb_i = (R' >> 2 i) & mask.
+template <int NW>
+struct WindowWords {
+    u32 s0, s1, s2;       // S' = S >> (128 - 2 s - 2 (NW - 1) - 2 K)
+    u32 r0, r1, r2;       // R' = revcomp(S) >> 2 s
+    __device__ __forceinline__ void init(u64 a, u64 b, u32 s, int K) {
+        shr128(a, b, 128u - 2u * s - 2u * (NW - 1) - 2u * (u32)K, s0, s1, s2);
+        const u64 rhi = rev_pairs(~b), rlo = rev_pairs(~a);
+        shr128(rhi, rlo, 2u * s, r0, r1, r2);
+    }
+    __device__ __forceinline__ u32 xhi(int i) const { return __builtin_amdgcn_alignbit(s2, s1, 2 * (NW - 1 - i)); }
+    __device__ __forceinline__ u32 xlo(int i) const { return __builtin_amdgcn_alignbit(s1, s0, 2 * (NW - 1 - i)); }
+    __device__ __forceinline__ u32 bhi(int i) const { return __builtin_amdgcn_alignbit(r2, r1, 2 * i); }
+    __device__ __forceinline__ u32 blo(int i) const { return __builtin_amdgcn_alignbit(r1, r0, 2 * i); }
+};
+
+// bit 63 - q of the result: the K bases from string position q on are all valid
+__device__ __forceinline__ u64 runs_of_k(u64 v, int K) {
+    int have = 1;
+    while (2 * have <= K) { v &= v << have; have *= 2; }
+    v &= v << (K - have);
+    return v;
+}
+
+// bit k of a 16-bit value -> bit 2 k
+__device__ __forceinline__ u32 spread16(u32 x) {
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+// ---------------------------------------------------------------------------------------
+// the histogram kernel
+// ---------------------------------------------------------------------------------------
+struct SHistArgs {
+    const u8* stream;
+    u64 n_bytes;
+    int K, mode;
+    PassPlan plan;
+    u32 binbase[MAX_PASSES];      // where pass p's bins start in LDS
+    u32 nbins;
+    u64* ghist;                   // [passes][gstride] += digit counts over the whole stream
+    u32 gstride;
+    u32* rows;                    // [ranges][1 << plan.bits[0]] += pass 0's digit counts per range
+    u64* acgt;                    // [4] or null
+    u64* rec_info;                // [0] = position of the stream's first newline (read); [1] += newline bytes, [2] += bad chunks
+    u64* sample;                  // or null: keys with (key >> sample_shift) == sample_value are also appended here ...
+    u32* sample_n;                // ... += 1 each (appended while below sample_cap)
+    u32 sample_cap;
+    int sample_shift;
+    u64 sample_value;
+    u32 ranges, split;            // grid = ranges * split: workgroup (w, s) takes every split-th tile of range w
+};
+
+// HI: every digit (and the sample test) looks only at key bits >= 32: the strands are compared on the high words alone --
+// hi(min(x, xb)) == min(hi x, hi xb) -- and the low words are never built.
+// TWO: the plan has exactly two passes (the usual one: two passes over the top bits, then the block dedupe), their digits in
+// scalar registers; otherwise the passes are walked through a table in LDS.
+template <bool HI, bool TWO>
+__global__ __launch_bounds__(SH_BLOCK, 4) void stream_hist_kernel(SHistArgs h) {
+    extern __shared__ u32 bins[];
+    __shared__ TileImage<SH_TILE> img;
+    __shared__ u32 pshift[MAX_PASSES], pmask[MAX_PASSES], pbase[MAX_PASSES];
+    const int tid = threadIdx.x;
+    for (u32 i = tid; i < h.nbins; i += SH_BLOCK) bins[i] = 0;
+    if (tid < MAX_PASSES) {
+        pshift[tid] = (u32)h.plan.shift[tid] - (HI ? 32u : 0u);
+        pmask[tid] = (1u << h.plan.bits[tid]) - 1u;
+        pbase[tid] = h.binbase[tid];
+    }
+    const u64 first_nl = h.rec_info[0];
+    const StreamTiling tl = make_tiling(h.n_bytes, first_nl, h.K, h.ranges);
+    const u32 w = blockIdx.x / h.split, sp = blockIdx.x % h.split;
+    const u64 B = (u64)w * tl.range_bytes;
+    const u64 E = (B + tl.range_bytes < h.n_bytes) ? B + tl.range_bytes : h.n_bytes;
+    const u32 ntile = B < E ? (u32)((E - B + SH_TILE - 1) / SH_TILE) : 0u;
+    const int K = h.K;
+    const int np = h.plan.passes;
+    const u64 mask = ~0ull >> (64 - 2 * K);
+    const u32 mlo = (u32)mask, mhi = (u32)(mask >> 32);
+    const bool canon = h.mode == ZK_KEYS_CANONICAL;
+    // TWO: the two digits
+    const u32 sh0 = (u32)h.plan.shift[0] - (HI ? 32u : 0u), sh1 = (u32)h.plan.shift[1] - (HI ? 32u : 0u);
+    const u32 dm0 = (1u << h.plan.bits[0]) - 1u, dm1 = (1u << h.plan.bits[1]) - 1u;
+    const u32 base1 = h.binbase[1];
+    const u32 nb0 = (u32)h.plan.bits[0], nb1 = (u32)h.plan.bits[1];
+    const u32 ssh = (u32)h.sample_shift - (HI ? 32u : 0u);
+    const typename std::conditional<HI, u32, u64>::type sval = (typename std::conditional<HI, u32, u64>::type)h.sample_value;
+    u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0, nl_count = 0, bad_count = 0;
+    // are the records uniform?  every chunk counts its newline bytes and whether they are exactly the expected separator
+    u32 rec = 0, m = 0, step_m = 0;
+    if (first_nl < 0x7fffffffull) {
+        rec = (u32)first_nl + 1u;
+        m = (u32)((B + (u64)sp * SH_TILE + 16ull * tid) % rec);
+        step_m = (u32)(((u64)h.split * SH_TILE) % rec);
+    }
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+    auto issue = [&](u32 j) {
+        const u64 P = B + (u64)j * SH_TILE;
+        q0 = load_chunk16(h.stream, h.n_bytes, P + 16ull * tid);
+        if (tid < 3) q1 = load_chunk16(h.stream, h.n_bytes, P + 16ull * (tid + SH_BLOCK));
+    };
+    if (sp < ntile) issue(sp);
+    __syncthreads();
+    for (u32 j = sp; j < ntile; j += h.split) {
+        const u64 off = B + (u64)j * SH_TILE + 16ull * tid;
+        const bool mine = off < E;          // chunks past the range's end belong to the next range
+        if (rec) {
+            if (mine) {
+                const u32 w4[4] = {q0.x, q0.y, q0.z, q0.w};
+                const int sep = (int)(rec - 1u) - (int)m;
+                const bool expect = sep >= 0 && sep < 16 && off + (u64)sep < h.n_bytes;
+                bool bad = false;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const u32 x = w4[q] ^ 0x0a0a0a0au;
+                    const u32 t = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
+                    nl_count += (u32)__popc(t);
+                    const u32 want = (expect && (sep >> 2) == q) ? (0x80u << (8 * (sep & 3))) : 0u;
+                    bad |= (t != want);
+                }
+                bad_count += bad ? 1u : 0u;
+            }
+            m += step_m;
+            if (m >= rec) m -= rec;
+        }
+        {
+            u32 cc, vv;
+            encode_swar16(q0, cc, vv);
+            img.codes[tid] = cc; img.valid[tid] = vv;
+            if (tid < 3) {
+                encode_swar16(q1, cc, vv);
+                img.codes[tid + SH_BLOCK] = cc; img.valid[tid + SH_BLOCK] = vv;
+            }
+        }
+        __syncthreads();
+        if (j + h.split < ntile) issue(j + h.split);
+        const u64 a = ((u64)img.codes[tid] << 32) | img.codes[tid + 1];
+        const u64 b = ((u64)img.codes[tid + 2] << 32) | img.codes[tid + 3];
+        u64 v = ((u64)img.valid[tid] << 48) | ((u64)img.valid[tid + 1] << 32) | ((u64)img.valid[tid + 2] << 16) | (u64)img.valid[tid + 3];
+        v = runs_of_k(v, K);
+        const u32 V16 = mine ? (u32)(v >> 48) : 0u;          // bit 15 - i: window i is a k-mer of this range
+        WindowWords<SH_NW> ww;
+        ww.init(a, b, 0u, K);
+        if (h.acgt) {
+            // acgt[x & 3] and acgt[xb & 3] over the valid windows: x & 3 is the window's last base, xb & 3 the complement of its first
+            const u32 Vs = spread16(V16);
+            const u32 ff = (u32)(a >> 32);                                               // bases 0 .. 15
+            const u32 fl = (u32)((K > 1 ? ((a << (2 * K - 2)) | (b >> (66 - 2 * K))) : a) >> 32);      // bases K - 1 .. K + 14
+            const u32 lf = ff & Vs, hf = (ff >> 1) & Vs, ll = fl & Vs, hl = (fl >> 1) & Vs;
+            a0 += (u32)__popc(Vs & ~hl & ~ll) + (u32)__popc(hf & lf);
+            a1 += (u32)__popc(~hl & ll) + (u32)__popc(hf & ~lf);
+            a2 += (u32)__popc(hl & ~ll) + (u32)__popc(~hf & lf);
+            a3 += (u32)__popc(hl & ll) + (u32)__popc(Vs & ~hf & ~lf);
+        }
+#pragma unroll
+        for (int i = 0; i < SH_NW; i++) {
+            const u32 inc = (V16 >> (15 - i)) & 1u;
+            // kd: the word the digits are taken from (HI: the key's high word)
+            typename std::conditional<HI, u32, u64>::type kd;
+            if constexpr (HI) {
+                const u32 xh = ww.xhi(i) & mhi, bh = ww.bhi(i) & mhi;
+                kd = canon ? (xh < bh ? xh : bh) : xh;
+            } else {
+                const u64 x = ((u64)(ww.xhi(i) & mhi) << 32) | (ww.xlo(i) & mlo), xb = ((u64)(ww.bhi(i) & mhi) << 32) | (ww.blo(i) & mlo);
+                kd = canon ? (x < xb ? x : xb) : x;
+            }
+            if constexpr (TWO && HI) {
+                atomicAdd(&bins[__builtin_amdgcn_ubfe(kd, sh0, nb0)], inc);
+                atomicAdd(&bins[base1 + __builtin_amdgcn_ubfe(kd, sh1, nb1)], inc);
+            } else if constexpr (TWO) {
+                atomicAdd(&bins[(u32)(kd >> sh0) & dm0], inc);
+                atomicAdd(&bins[base1 + ((u32)(kd >> sh1) & dm1)], inc);
+            } else {
+                for (int p = 0; p < np; p++) atomicAdd(&bins[pbase[p] + ((u32)(kd >> pshift[p]) & pmask[p])], inc);
+            }
+            if (h.sample) {
+                const bool hit = (kd >> ssh) == sval && inc;
+                if (__builtin_amdgcn_ballot_w64(hit)) {          // rare: four blocks of 2^18
+                    if (hit) {
+                        const u64 x = (((u64)ww.xhi(i) << 32) | ww.xlo(i)) & mask, xb = (((u64)ww.bhi(i) << 32) | ww.blo(i)) & mask;
+                        const u64 kk = canon ? (x < xb ? x : xb) : x;
+                        const u32 at = atomicAdd(h.sample_n, 1u);
+                        if (at < h.sample_cap) h.sample[at] = kk;
+                    }
+                }
+            }
+        }
+        __syncthreads();          // the image is restaged by the next iteration
+    }
+    __syncthreads();
+    const u32 r0 = 1u << h.plan.bits[0];
+    for (u32 i = tid; i < h.nbins; i += SH_BLOCK) {
+        const u32 c = bins[i];
+        if (!c) continue;
+        if (i < r0) atomicAdd(&h.rows[(u64)w * r0 + i], c);
+        int p = 0;          // the pass bin i belongs to
+        for (int q = 1; q < np; q++) if (i >= pbase[q]) p = q;
+        atomicAdd(&h.ghist[(u64)p * h.gstride + (i - pbase[p])], (u64)c);
+    }
+    if (rec) {
+        nl_count = wave_sum_u32(nl_count); bad_count = wave_sum_u32(bad_count);
+        if ((tid & 63) == 0) {
+            if (nl_count) atomicAdd(&h.rec_info[1], (u64)nl_count);
+            if (bad_count) atomicAdd(&h.rec_info[2], (u64)bad_count);
+        }
+    }
+    if (h.acgt) {
+        a0 = wave_sum_u32(a0); a1 = wave_sum_u32(a1); a2 = wave_sum_u32(a2); a3 = wave_sum_u32(a3);
+        if ((tid & 63) == 0) {
+            if (a0) atomicAdd(&h.acgt[0], (u64)a0);
+            if (a1) atomicAdd(&h.acgt[1], (u64)a1);
+            if (a2) atomicAdd(&h.acgt[2], (u64)a2);
+            if (a3) atomicAdd(&h.acgt[3], (u64)a3);
+        }
+    }
+}
+
+// offs[w][d] = ghist0[d] (exclusive prefix over the digits, already in place) + rows[0 .. w)[d]
+__global__ void rows_scan_kernel(const u32* __restrict__ rows, const u64* __restrict__ ghist0, u32 ranges, u32 radix, u64* __restrict__ offs) {
+    const u32 d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= radix) return;
+    u64 run = ghist0[d];
+    for (u32 w = 0; w < ranges; w++) {
+        offs[(u64)w * radix + d] = run;
+        run += rows[(u64)w * radix + d];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// the pass
+// ---------------------------------------------------------------------------------------
+struct P0Args {
+    const u8* stream;
+    u64 n_bytes;
+    int K, mode;
+    StreamTiling tl;
+    int by_record;        // the host has seen the histogram kernel's verdict: threads follow the records (else positions)
+    int shift, bits;
+    const u64* offs;      // [ranges][1 << bits]
+    const u32* rows;      // [ranges][1 << bits]: checked against what the pass wrote
+    u64* kout;
+    u64 n;                // keys in all: nothing is ever stored at or beyond it
+    u32* err;
+    u64* dbg;             // or null (zk_debug_buffer): [ranges][16] time (s_memtime ticks) wave 0 of the range spent per phase, summed over its tiles
+};
+// phase accounting for tools/p0_phases.py: a handful of scalar instructions per tile when off
+#define P0_PHASE(k) do { if (a.dbg) { const u64 now__ = __builtin_amdgcn_s_memtime(); ph[k] += now__ - tlast; tlast = now__; } } while (0)
+
+template <int RBITS, int G, bool ALIGN>
+struct P0Smem {
+    static constexpr int RADIX = 1 << RBITS, CAP = P0_TILE + (ALIGN ? 2 : 1) * RADIX * (G - 1);
+    u64 exch[CAP];                 // the tile, grouped by digit; what is left of a digit stays here until the next tile
+    u32 codes[2][P0_IMG_WORDS], valid[2][P0_IMG_WORDS];          // the 2-bit image of this tile and of the next
+    u32 cnt[RADIX];                // keys of the digit: the left-over ones between tiles, all of them after the ranking
+    u32 offlen[RADIX];             // (keys of the digit that leave with this tile) << 16 | where its keys start in exch
+    u32 tail[RADIX];               // (left-over keys of the digit) << 16 | where they start in exch
+    u64 gbase[RADIX];              // output index of exch slot 0 as seen by this digit
+    u64 gcur[RADIX];               // the digit's next output index
+    u32 wsum[P0_BLOCK / 64];
+    u32 total;
+};
+
+template <int RBITS, int G, bool ALIGN>
+__global__ __launch_bounds__(P0_BLOCK, 1) void stream_pass0_kernel(P0Args a) {
+    using S = P0Smem<RBITS, G, ALIGN>;
+    constexpr int RADIX = S::RADIX, NW = P0_NW, BLOCK = P0_BLOCK;
+    static_assert(S::CAP < 65536, "slot numbers are 16-bit");
+    __shared__ S sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 w = blockIdx.x;
+    const u32 radix = 1u << a.bits;
+    const u64 B = (u64)w * a.tl.range_bytes;
+    if (B >= a.n_bytes) return;
+    const u64 E = (B + a.tl.range_bytes < a.n_bytes) ? B + a.tl.range_bytes : a.n_bytes;
+    const u32 tile_bytes = a.by_record ? a.tl.tile_bytes : (u32)P0_TILE;
+    const u32 ntile = (u32)((E - B + tile_bytes - 1) / tile_bytes);
+    const u32 nch = tile_bytes / 16 + 3;          // 16-byte chunks of a tile with its halo
+    const int K = a.K;
+    const u64 mask = ~0ull >> (64 - 2 * K);
+    const u32 mlo = (u32)mask, mhi = (u32)(mask >> 32);
+    const u32 dmask = radix - 1u;
+    if (tid < RADIX) {
+        sm.cnt[tid] = 0; sm.tail[tid] = 0; sm.offlen[tid] = 0;
+        sm.gcur[tid] = (u32)tid < radix ? a.offs[(u64)w * radix + tid] : 0ull;
+    }
+    // this thread's windows inside a tile: NW consecutive ones from tile position p0 on
+    u32 p0 = (u32)NW * tid, wlim = (1u << NW) - 1u;          // wlim: which of them exist at all
+    if (a.by_record) {
+        const u32 r = (u32)(((u64)tid * a.tl.cpr_inv) >> 32), j = tid - r * a.tl.cpr;
+        p0 = r * a.tl.rec + (u32)NW * j;
+        const int left = (int)a.tl.wpr - NW * (int)j;
+        wlim = (r < a.tl.rpt) ? ((left >= NW) ? (1u << NW) - 1u : ((1u << (left > 0 ? left : 0)) - 1u)) : 0u;
+        if (r >= a.tl.rpt) p0 = 0;
+    }
+    // The image of tile t + 1 is made, and the bytes of tile t + 2 are asked for, BEFORE the stores of tile t are issued: a wait for
+    // loaded bytes then never has this tile's stores in front of it (the memory counter is one for loads and stores).
+    uint4 q = make_uint4(0, 0, 0, 0);
+    if ((u32)tid < nch) {
+        q = load_chunk16(a.stream, a.n_bytes, B + 16ull * tid);
+        u32 cc, vv;
+        encode_swar16(q, cc, vv);
+        sm.codes[0][tid] = cc; sm.valid[0][tid] = vv;
+        if (ntile > 1) q = load_chunk16(a.stream, a.n_bytes, B + tile_bytes + 16ull * tid);
+    }
+    __syncthreads();
+    u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u64 tlast = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
+    for (u32 t = 0; t < ntile; t++) {
+        const u64 T0 = B + (u64)t * tile_bytes;
+        const bool last = t + 1 == ntile;
+        const u32* codes = sm.codes[t & 1];
+        const u32* valid = sm.valid[t & 1];
+        // ---- this thread's keys ---------------------------------------------------------------------
+        u64 key[NW];
+        u32 live;
+        {
+            const u32 j = p0 >> 4, s = p0 & 15u;
+            const u64 sa = ((u64)codes[j] << 32) | codes[j + 1];
+            const u64 sb = ((u64)codes[j + 2] << 32) | codes[j + 3];
+            u64 v = ((u64)valid[j] << 48) | ((u64)valid[j + 1] << 32) | ((u64)valid[j + 2] << 16) | (u64)valid[j + 3];
+            v = runs_of_k(v, K);
+            // bit i: window i is a k-mer (of this range: windows from E on belong to the next one)
+            live = (__brev((u32)((v << s) >> (64 - NW))) >> (32 - NW)) & wlim;
+            if (T0 + p0 >= E) live = 0;
+            WindowWords<NW> ww;
+            ww.init(sa, sb, s, K);
+#pragma unroll
+            for (int i = 0; i < NW; i++) {
+                const u64 x = ((u64)(ww.xhi(i) & mhi) << 32) | (ww.xlo(i) & mlo), xb = ((u64)(ww.bhi(i) & mhi) << 32) | (ww.blo(i) & mlo);
+                key[i] = (a.mode == ZK_KEYS_CANONICAL) ? (x < xb ? x : xb) : x;
+            }
+        }
+        // ---- what the last tile left of this thread's digit: into registers, the park below moves it ----------
+        u64 ck[G - 1];
+        u32 nck = 0;
+        if (tid < RADIX) {
+            // (the count comes from `tail`, not from cnt: the ranking of this tile is already adding to cnt)
+            const u32 tl = sm.tail[tid];
+            nck = tl >> 16;
+            const u32 at = tl & 0xffffu;
+#pragma unroll
+            for (int j = 0; j < G - 1; j++) ck[j] = (u32)j < nck ? sm.exch[at + j] : 0ull;
+        }
+        // ---- rank: the digit's counter hands out the places (no order to keep) ------------------------------
+        u32 rk[NW];
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            const u32 d = (u32)(key[i] >> a.shift) & dmask;
+            rk[i] = ((live >> i) & 1u) ? atomicAdd(&sm.cnt[d], 1u) : 0u;
+        }
+        P0_PHASE(0);          // keys made, ranks asked for
+        __syncthreads();
+        P0_PHASE(1);          // ... waiting for the other waves
+        // ---- per digit: how many keys leave now, where the digit sits in LDS --------------------------------
+        u32 tot = 0, flen = 0, front = 0, size = 0;
+        u64 F = 0;
+        if (tid < RADIX) {
+            tot = sm.cnt[tid];
+            F = sm.gcur[tid];
+            const u64 end = F + tot;
+            u64 Eo = last ? end : (end & ~(u64)(G - 1));
+            if (Eo < F) Eo = F;
+            flen = (u32)(Eo - F);
+            front = ALIGN ? (u32)(F & (G - 1)) : 0u;          // slots skipped so that output units are units of slots as well
+            size = ALIGN ? ((front + tot + G - 1) & ~(u32)(G - 1)) : tot;
+        }
+        const u32 inc = wave_incl_scan_u32(size);
+        if (lane == 63) sm.wsum[wave] = inc;
+        __syncthreads();
+        u32 woff = 0;
+        for (int q2 = 0; q2 < wave; q2++) woff += sm.wsum[q2];
+        const u32 A = woff + inc - size;          // where the digit's region starts
+        if (tid == BLOCK - 1) sm.total = woff + inc;
+        if (tid < RADIX) {
+            const u32 O = A + front;
+            sm.offlen[tid] = (flen << 16) | O;
+            sm.gbase[tid] = F - O;
+            sm.gcur[tid] = F + flen;
+            sm.cnt[tid] = tot - flen;
+            sm.tail[tid] = ((tot - flen) << 16) | (O + flen);
+        }
+        __syncthreads();
+        P0_PHASE(2);          // scan over the digits (two barriers)
+        // ---- park ----------------------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            const u32 d = (u32)(key[i] >> a.shift) & dmask;
+            if ((live >> i) & 1u) sm.exch[(sm.offlen[d] & 0xffffu) + rk[i]] = key[i];
+        }
+        if (tid < RADIX) {
+            const u32 O = A + front;
+#pragma unroll
+            for (int j = 0; j < G - 1; j++) if ((u32)j < nck) sm.exch[O + j] = ck[j];
+            if (ALIGN) {
+                // the slots of the region that hold no key get one of this digit that is never stored (outside [O, O + flen))
+                const u64 fill = (u64)tid << a.shift;
+                for (u32 j = 0; j < front; j++) sm.exch[A + j] = fill;
+                for (u32 j = O + tot; j < A + size; j++) sm.exch[j] = fill;
+            }
+        }
+        P0_PHASE(3);          // parked
+        __syncthreads();
+        P0_PHASE(4);          // ... waiting
+        // ---- the next tile's image; the bytes of the tile after it ------------------------------------------
+        if (!last && (u32)tid < nch) {
+            u32 cc, vv;
+            encode_swar16(q, cc, vv);
+            sm.codes[(t + 1) & 1][tid] = cc; sm.valid[(t + 1) & 1][tid] = vv;
+            if (t + 2 < ntile) q = load_chunk16(a.stream, a.n_bytes, T0 + 2ull * tile_bytes + 16ull * tid);
+        }
+        P0_PHASE(5);          // next image (includes the wait for its bytes)
+        // ---- whole units out ----------------------------------------------------------------------------
+        const u32 total = sm.total;
+#pragma unroll 4
+        for (u32 p = (u32)tid; p < total; p += BLOCK) {
+            const u64 k = sm.exch[p];
+            const u32 d = (u32)(k >> a.shift) & dmask;
+            const u32 ol = sm.offlen[d];
+            if (p - (ol & 0xffffu) < (ol >> 16)) {
+                const u64 pos = sm.gbase[d] + p;
+                if (pos < a.n) a.kout[pos] = k; else atomicOr(a.err, ZK_DERR_MISMATCH);
+            }
+        }
+        P0_PHASE(6);          // stores issued
+        __syncthreads();          // the next image is whole; nobody still reads what the next tile's scan and park rewrite
+        P0_PHASE(7);          // ... waiting
+    }
+    if (a.dbg && tid == 0) {
+        for (int k = 0; k < 8; k++) a.dbg[(u64)w * 16 + k] = ph[k];
+        a.dbg[(u64)w * 16 + 8] = ntile;
+    }
+    __syncthreads();
+    if ((u32)tid < radix && (sm.gcur[tid] != a.offs[(u64)w * radix + tid] + a.rows[(u64)w * radix + tid] || sm.cnt[tid] != 0))
+        atomicOr(a.err, ZK_DERR_MISMATCH);
+}
+
+// ---------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------
+int stream_ranges(zk_ctx* c) { return c->stream_ranges > 0 ? c->stream_ranges : (c->num_cus > 0 ? c->num_cus : 1); }
+
+// histogram of every pass's digit + acgt + the uniformity check + (optionally) the set-aside blocks, and pass 0's digit counts per
+// range.  ghist: [MAX_PASSES][gstride] (zeroed here; exclusive prefixes on return, the key count in *d_n).
+int stream_hist(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, const PassPlan& plan, u64* ghist, u32 gstride,
+                u64* d_acgt, u64* d_n, u64* rec_info, u64* sample, u32 sample_cap, int sample_shift, u64 sample_value, u32* sample_n,
+                StreamRows* out) {
+    SHistArgs h = {};
+    h.stream = stream; h.n_bytes = n_bytes; h.K = K; h.mode = mode; h.plan = plan;
+    u32 nb = 0;
+    bool hi = 2 * K > 32;
+    for (int p = 0; p < plan.passes; p++) { h.binbase[p] = nb; nb += 1u << plan.bits[p]; if (plan.shift[p] < 32) hi = false; }
+    if (sample && sample_shift < 32) hi = false;
+    h.nbins = nb;
+    h.ghist = ghist; h.gstride = gstride;
+    h.acgt = d_acgt; h.rec_info = rec_info;
+    h.sample = sample; h.sample_n = sample_n; h.sample_cap = sample_cap; h.sample_shift = sample_shift; h.sample_value = sample_value;
+    h.ranges = (u32)stream_ranges(c);
+    h.split = 8;
+    const u32 r0 = 1u << plan.bits[0];
+    u32* rows; u64* offs;
+    ZK_TRY(arena_alloc(c, sizeof(u32) * (uint64_t)h.ranges * r0, (void**)&rows));
+    ZK_TRY(arena_alloc(c, sizeof(u64) * (uint64_t)h.ranges * r0, (void**)&offs));
+    h.rows = rows;
+    ZK_HIP(c, hipMemsetAsync(rows, 0, sizeof(u32) * (uint64_t)h.ranges * r0, c->stream));
+    ZK_HIP(c, hipMemsetAsync(ghist, 0, sizeof(u64) * MAX_PASSES * gstride, c->stream));
+    if (d_acgt) ZK_HIP(c, hipMemsetAsync(d_acgt, 0, sizeof(u64) * 4, c->stream));
+    const u32 grid = h.ranges * h.split;
+    prof_begin(c, ZK_PROF_HIST_STREAM, n_bytes);
+    const bool two = plan.passes == 2;
+    if (hi && two) hipLaunchKernelGGL((stream_hist_kernel<true, true>), dim3(grid), dim3(SH_BLOCK), nb * sizeof(u32), c->stream, h);
+    else if (hi) hipLaunchKernelGGL((stream_hist_kernel<true, false>), dim3(grid), dim3(SH_BLOCK), nb * sizeof(u32), c->stream, h);
+    else if (two) hipLaunchKernelGGL((stream_hist_kernel<false, true>), dim3(grid), dim3(SH_BLOCK), nb * sizeof(u32), c->stream, h);
+    else hipLaunchKernelGGL((stream_hist_kernel<false, false>), dim3(grid), dim3(SH_BLOCK), nb * sizeof(u32), c->stream, h);
+    prof_end(c);
+    ZK_HIP(c, hipGetLastError());
+    out->rows = rows; out->offs = offs; out->ranges = h.ranges; out->radix = r0;
+    return ZK_OK;
+}
+
+// after the exclusive prefix of pass 0's digits is in ghist0 and the host has read the verdict on the records
+int stream_pass0(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, int shift, int bits, const u64* ghist0, const StreamRows& rows,
+                 uint64_t first_nl, bool uniform, u64* kout, uint64_t n, int variant) {
+    if (bits < 1 || (1u << bits) != rows.radix) return fail(c, ZK_EINTERNAL, "stream_pass0: %d digit bits, rows of %u", bits, rows.radix);
+    hipLaunchKernelGGL(rows_scan_kernel, dim3((rows.radix + 255) / 256), dim3(256), 0, c->stream, rows.rows, ghist0, rows.ranges, rows.radix, rows.offs);
+    P0Args a = {};
+    a.stream = stream; a.n_bytes = n_bytes; a.K = K; a.mode = mode;
+    a.tl = make_tiling(n_bytes, first_nl, K, rows.ranges);
+    a.by_record = (uniform && a.tl.rec) ? 1 : 0;
+    a.shift = shift; a.bits = bits; a.offs = rows.offs; a.rows = rows.rows; a.kout = kout; a.n = n; a.err = c->d_err; a.dbg = c->dbg;
+    prof_begin(c, ZK_PROF_PASS_STREAM, n_bytes + 8 * n);
+    if (bits <= 9 && variant == 2) hipLaunchKernelGGL((stream_pass0_kernel<9, 16, false>), dim3(rows.ranges), dim3(P0_BLOCK), 0, c->stream, a);
+    else if (bits <= 9 && variant == 3) hipLaunchKernelGGL((stream_pass0_kernel<9, 8, false>), dim3(rows.ranges), dim3(P0_BLOCK), 0, c->stream, a);
+    else if (bits <= 9) hipLaunchKernelGGL((stream_pass0_kernel<9, 8, true>), dim3(rows.ranges), dim3(P0_BLOCK), 0, c->stream, a);
+    else return fail(c, ZK_EINTERNAL, "stream_pass0: %d digit bits", bits);
+    prof_end(c);
+    ZK_HIP(c, hipGetLastError());
+    return ZK_OK;
+}
+
+}  // namespace zk

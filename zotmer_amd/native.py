@@ -316,7 +316,11 @@ class Context:
                  "union_sum": 7, "select": 8, "mirror": 9, "intersect": 10, "count_hist": 11, "pass_packed": 12, "sample": 13}
 
     def tune(self, sort_variant=None, pairs_variant=None, short_sort=None, side_div=None, xcd_group=None, comm_chunk=None,
-             early_collapse=None, packed_pairs=None, wide_tiles=None):
+             early_collapse=None, packed_pairs=None, wide_tiles=None, stream_pass=None, stream_ranges=None):
+        if stream_pass is not None:
+            self._check(self.lib.zk_tune(self.h, 10, int(stream_pass)))
+        if stream_ranges is not None:
+            self._check(self.lib.zk_tune(self.h, 11, int(stream_ranges)))
         if wide_tiles is not None:
             self._check(self.lib.zk_tune(self.h, 9, int(wide_tiles)))
         if packed_pairs is not None:
