@@ -77,7 +77,7 @@ int zk_upload_async(zk_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 #define ZK_TUNE_PACKED_PAIRS 8   /* zk_kmerize / zk_mirror_expand: 1 (default) = (k-mer, count) pairs travel as one 64-bit word when the counts fit the bits above 2K */
 #define ZK_TUNE_WIDE_TILES 9     /* radix sort: 1 (default) = array passes over up to 3 * 2^30 keys use 16 K-key tiles, one workgroup per CU */
 #define ZK_TUNE_STREAM_PASS 10   /* the first sort pass of zk_kmerize / zk_sort_stream: 1 (default) = static stream ranges, whole 64-byte units written
-                                  * out of LDS (stream_pass.hip); 2 / 3 = the same with other unit sizes (measurements); 0 = the look-back pipeline */
+                                  * out of LDS (stream_pass.hip); 2 = the same with 32-byte units (measurements); 0 = the look-back pipeline */
 #define ZK_TUNE_STREAM_RANGES 11 /* ... the number of ranges the stream is cut into, one workgroup each (0 = one per CU, the default; <= 4096) */
 #define ZK_TUNE_COMM_CHUNK 6     /* zk_all_to_all_v: bytes per message and round (0 = 256 MiB, the default) */
 int zk_tune(zk_ctx* ctx, int what, int value);

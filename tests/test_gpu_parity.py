@@ -436,7 +436,7 @@ def test_kmerize_stream_ranges_pass(ctx, shape):
     d = ctx.upload_stream(stream_of(reads))
     try:
         for ranges in (3, 7, 0):
-            for variant in (1, 2, 3, 0):
+            for variant in (1, 2, 0):
                 for collapse in ((1, 0) if variant == 1 else (1,)):
                     ctx.tune(stream_pass=variant, stream_ranges=ranges, early_collapse=collapse)
                     k, c, st = ctx.kmerize(d, K)

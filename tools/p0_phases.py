@@ -14,7 +14,10 @@ ctx = native.Context(0)
 ctx.tune(stream_pass=variant)
 d = ctx.synth_reads(synth.DEFAULT_SEED, 0, reads, cfg["L"], genome=cfg["genome"], sub_thr=synth.frac32(cfg["sub"]), n_thr=synth.frac32(cfg["n"]))
 ctx.kmerize(d, K)
-dbg = ctx.empty(4096 * 16, np.uint64)
+mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0          # 1: the pass without its stores, 2: the stores of a range's first tile only, repeated
+ranges = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+ctx.tune(stream_pass=variant | (mode << 8), stream_ranges=ranges)
+dbg = ctx.upload(np.zeros(4096 * 16, np.uint64))
 ctx._check(ctx.lib.zk_debug_buffer(ctx.h, dbg.ptr))
 ctx.profile(True)
 ctx.kmerize(d, K)
@@ -24,10 +27,10 @@ ctx.profile(False)
 ctx._check(ctx.lib.zk_debug_buffer(ctx.h, None))
 raw = dbg.to_host().reshape(4096, 16).astype(np.float64)
 raw = raw[raw[:, 8] > 0]
-names = ["keys + rank", "barrier", "scan (2 barriers)", "park", "barrier", "next image (+ wait for bytes)", "stores issued", "barrier"]
+names = ["0 keys + rank", "1 barrier", "2 scan (2 barriers)", "3 park", "4 barrier", "5 next image (+ wait for bytes)", "6 stores issued", "7 barrier"]
 tiles = raw[:, 8].sum()
 per = raw[:, :8].sum(axis=0) / tiles * 10.0          # ns per tile
-out = {"reads": reads, "variant": variant, "K": K, "ranges": int(len(raw)), "tiles_per_range": float(raw[:, 8].mean()),
+out = {"reads": reads, "variant": variant, "mode": mode, "K": K, "ranges": int(len(raw)), "tiles_per_range": float(raw[:, 8].mean()),
        "ns_per_tile": {n: round(float(v), 1) for n, v in zip(names, per)}, "ns_per_tile_total": round(float(per.sum()), 1),
        "hist_stream_ms": prof.get("hist_stream", {}).get("ms"), "pass_stream_ms": prof.get("pass_stream", {}).get("ms")}
 print(json.dumps(out))

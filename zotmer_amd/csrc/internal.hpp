@@ -27,7 +27,7 @@ struct zk_ctx {
     int side_div = 8;          // ... side list capacity = n / side_div (tests shrink it to force the fallback)
     int pairs_variant = 2;     // ... for (key, u32) pairs
     int stream_pass = 1;       // the first sort pass (from the base stream): 1 = static ranges, whole 64-byte units written from LDS
-                               // (stream_pass.hip; 2, 3 = its other unit sizes, for measurements), 0 = the look-back pipeline
+                               // (stream_pass.hip; 2 = 32-byte units, for measurements), 0 = the look-back pipeline
     int stream_ranges = 0;     // ... ranges the stream is cut into (0 = one per CU; tests use a few so that a range has many tiles)
 
     // workspace arena: a bump allocator reset at the start of every API call
@@ -153,11 +153,11 @@ int collapse_pass(zk_ctx* c, const u64* keys, uint64_t n, int shift, int bits, i
 int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,
                 uint64_t acgt[4], u64** result);
 // stream_pass.hip: histogram + first pass over static stream ranges
-struct StreamRows { u32* rows = nullptr; u64* offs = nullptr; u32 ranges = 0, radix = 0; };
+struct StreamRows { u32* rows = nullptr; u64* offs = nullptr; u32 ranges = 0, radix = 0; u32* gcodes = nullptr; u16* gvalid = nullptr; };
 int stream_hist(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, const PassPlan& plan, u64* ghist, u32 gstride,
                 u64* d_acgt, u64* d_n, u64* rec_info, u64* sample, u32 sample_cap, int sample_shift, u64 sample_value, u32* sample_n,
-                StreamRows* out);
-int stream_pass0(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, int shift, int bits, const u64* ghist0, const StreamRows& rows,
+                void* image_room, uint64_t image_room_bytes, StreamRows* out);
+int stream_pass0(zk_ctx* c, uint64_t n_bytes, int K, int mode, int shift, int bits, const u64* ghist0, const StreamRows& rows,
                  uint64_t first_nl, bool uniform, u64* kout, uint64_t n, int variant);
 // select.hip
 int trim(zk_ctx* c, const u64* keys, const void* cnts, int cbits, uint64_t n, u64 lo, u64 hi, u64* ok, void* oc,

@@ -1903,7 +1903,9 @@ struct Sorter {
             hipLaunchKernelGGL(first_newline_kernel, dim3(1), dim3(256), 0, c->stream, src.stream, (u64)src.n_bytes, rec_info);
             ZK_TRY(stream_hist(c, src.stream, src.n_bytes, src.K, src.mode, plan, ghist, (u32)C::RADIX, d_acgt, d_n, rec_info,
                                sampling ? buf_b : nullptr, sample_cap, sampling ? src.sample->shift : 0, sampling ? src.sample->value : 0,
-                               (u32*)(c->d_scalars + 23), &srows));
+                               (u32*)(c->d_scalars + 23),
+                               // the stream's image goes behind the set-aside keys in the second sort buffer (idle until pass 1)
+                               (char*)buf_b + (sampling ? 24ull * sample_cap : 0), 8 * cap - (sampling ? 24ull * sample_cap : 0), &srows));
             hipLaunchKernelGGL(hist_scan_kernel, dim3(1), dim3(256), 0, c->stream, ghist, plan.passes, (int)C::RADIX, d_n);
             ZK_HIP(c, hipGetLastError());
         } else {
@@ -1936,8 +1938,9 @@ struct Sorter {
         if (ranged) {
             const uint64_t first_nl = c->h_scalars[20], nl = c->h_scalars[21], bad = c->h_scalars[22];
             const bool uniform = first_nl < 0x7fffffffull && src.n_bytes % (first_nl + 1) == 0 && bad == 0 && nl == src.n_bytes / (first_nl + 1);
-            ZK_TRY(stream_pass0(c, src.stream, src.n_bytes, src.K, src.mode, plan.shift[0], plan.bits[0], ghist, srows, first_nl, uniform, buf_a, n,
+            ZK_TRY(stream_pass0(c, src.n_bytes, src.K, src.mode, plan.shift[0], plan.bits[0], ghist, srows, first_nl, uniform, buf_a, n,
                                 c->stream_pass));
+            if (c->stream_pass >> 8) { *n_keys = 0; return ZK_OK; }          // measurement modes of the pass (tools/p0_phases.py): its output is not for use
         } else
         if constexpr (C::PIPE && C::ITEMS == 16 && PipeSmem<C>::IMG_FITS && C::BLOCK <= 512) {
             // Uniform records (checked by the histogram kernel: the only newlines are one every `rec` bytes): tiles follow

@@ -24,7 +24,7 @@
 
 namespace zk {
 
-constexpr int P0_BLOCK = 1024, P0_NW = 8, P0_TILE = P0_BLOCK * P0_NW, P0_IMG_WORDS = 640;
+constexpr int P0_BLOCK = 512, P0_NW = 8, P0_TILE = P0_BLOCK * P0_NW, P0_IMG_WORDS = 320;          // the pass: 2 workgroups per CU
 constexpr int SH_BLOCK = 512, SH_NW = 16, SH_TILE = SH_BLOCK * SH_NW;          // the histogram kernel's tiles: positions
 
 // How the stream is cut.  Decided from the position of the stream's first newline alone (the histogram kernel runs before
@@ -162,6 +162,8 @@ struct SHistArgs {
     int sample_shift;
     u64 sample_value;
     u32 ranges, split;            // grid = ranges * split: workgroup (w, s) takes every split-th tile of range w
+    u32* gcodes;                  // [ceil(n_bytes / 16)] the stream's 2-bit image, 16 bases per word (first base on top) ...
+    u16* gvalid;                  // ... and which of them are bases: the pass reads these instead of encoding the bytes again
 };
 
 // HI: every digit (and the sample test) looks only at key bits >= 32: the strands are compared on the high words alone --
@@ -240,6 +242,7 @@ __global__ __launch_bounds__(SH_BLOCK, 4) void stream_hist_kernel(SHistArgs h) {
             u32 cc, vv;
             encode_swar16(q0, cc, vv);
             img.codes[tid] = cc; img.valid[tid] = vv;
+            if (mine && h.gcodes) { h.gcodes[off >> 4] = cc; h.gvalid[off >> 4] = (u16)vv; }
             if (tid < 3) {
                 encode_swar16(q1, cc, vv);
                 img.codes[tid + SH_BLOCK] = cc; img.valid[tid + SH_BLOCK] = vv;
@@ -343,9 +346,10 @@ __global__ void rows_scan_kernel(const u32* __restrict__ rows, const u64* __rest
 // the pass
 // ---------------------------------------------------------------------------------------
 struct P0Args {
-    const u8* stream;
+    const u32* gcodes;    // the stream's 2-bit image and validity bits, one word / half word per 16 bytes (the histogram kernel wrote them)
+    const u16* gvalid;
     u64 n_bytes;
-    int K, mode;
+    int K;
     StreamTiling tl;
     int by_record;        // the host has seen the histogram kernel's verdict: threads follow the records (else positions)
     int shift, bits;
@@ -354,30 +358,52 @@ struct P0Args {
     u64* kout;
     u64 n;                // keys in all: nothing is ever stored at or beyond it
     u32* err;
+    int split_stores;     // 1: a tile's units leave in two bursts (see the kernel)
+    int dbg_mode;         // measurements only (results are wrong): 1 = no stores, 2 = after a range's first tile only the stores (its keys again and again)
     u64* dbg;             // or null (zk_debug_buffer): [ranges][16] time (s_memtime ticks) wave 0 of the range spent per phase, summed over its tiles
 };
 // phase accounting for tools/p0_phases.py: a handful of scalar instructions per tile when off
-#define P0_PHASE(k) do { if (a.dbg) { const u64 now__ = __builtin_amdgcn_s_memtime(); ph[k] += now__ - tlast; tlast = now__; } } while (0)
+#define P0_PHASE(k) do { if (a.dbg) { const u32 now__ = (u32)__builtin_amdgcn_s_memtime(); ph[k] += now__ - tlast; tlast = now__; } } while (0)
 
-template <int RBITS, int G, bool ALIGN>
+// inclusive prefix sum over the 64 lanes with DPP moves (row shifts, then the two row broadcasts of gfx9): no LDS round trips
+__device__ __forceinline__ u32 wave_incl_scan_dpp(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);          // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);          // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);          // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);          // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);          // row_bcast:15 into rows 1 and 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);          // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// A unit of the output: up to G keys that lie side by side in exch and go to G consecutive, G-aligned places of the output (the
+// first unit of a digit's piece may start off the grid, the last may be short).  One word: slot | (keys - 1) << 14 | digit << 18;
+// the place in the output is gbase[digit] + slot.
+__device__ __forceinline__ u32 unit_pack(u32 slot, u32 len, u32 digit) { return slot | ((len - 1u) << 14) | (digit << 18); }
+
+template <int RBITS, int G>
 struct P0Smem {
-    static constexpr int RADIX = 1 << RBITS, CAP = P0_TILE + (ALIGN ? 2 : 1) * RADIX * (G - 1);
-    u64 exch[CAP];                 // the tile, grouped by digit; what is left of a digit stays here until the next tile
-    u32 codes[2][P0_IMG_WORDS], valid[2][P0_IMG_WORDS];          // the 2-bit image of this tile and of the next
-    u32 cnt[RADIX];                // keys of the digit: the left-over ones between tiles, all of them after the ranking
-    u32 offlen[RADIX];             // (keys of the digit that leave with this tile) << 16 | where its keys start in exch
-    u32 tail[RADIX];               // (left-over keys of the digit) << 16 | where they start in exch
+    static constexpr int RADIX = 1 << RBITS, CAP = P0_TILE + RADIX * (G - 1), UNITS = CAP / G + 2 * RADIX;
+    u64 exch[CAP + 64];            // the tile, grouped by digit; what is left of a digit stays here until the next tile
+                                   // (+ one slot per lane for the writes of windows that are no k-mers: no branch around an LDS access)
     u64 gbase[RADIX];              // output index of exch slot 0 as seen by this digit
-    u64 gcur[RADIX];               // the digit's next output index
-    u32 wsum[P0_BLOCK / 64];
-    u32 total;
+    u32 units[UNITS];              // what leaves with this tile
+    u32 codes[P0_IMG_WORDS], valid[P0_IMG_WORDS];          // the 2-bit image of the tile whose keys are made next
+    u32 cnt[RADIX + 64];           // keys of the digit: the left-over ones between tiles, all of them after the ranking (+ 64 for the dead)
+    u16 off[RADIX];                // where the digit's keys start in exch
+    u16 nu[RADIX];                 // units of the digit
+    u32 nunits;
 };
 
-template <int RBITS, int G, bool ALIGN>
-__global__ __launch_bounds__(P0_BLOCK, 1) void stream_pass0_kernel(P0Args a) {
-    using S = P0Smem<RBITS, G, ALIGN>;
+// One digit per thread (RADIX == P0_BLOCK): the digit's output cursor and its left-over keys' place are that thread's registers.
+// CANON: the key is min(x, rc x) (else x).  FAST: 2 K > 32 and the digit lies in the key's high word (the usual plan): no mask on the
+// low words, the digit is one bit-field extract.
+template <int RBITS, int G, bool CANON, bool FAST>
+__global__ __launch_bounds__(P0_BLOCK, 4) void stream_pass0_kernel(P0Args a) {
+    using S = P0Smem<RBITS, G>;
     constexpr int RADIX = S::RADIX, NW = P0_NW, BLOCK = P0_BLOCK;
-    static_assert(S::CAP < 65536, "slot numbers are 16-bit");
+    static_assert(S::CAP < (1 << 14) && G <= 16 && RBITS <= 14, "unit_pack");
+    static_assert(RADIX == BLOCK && (G & (G - 1)) == 0 && 64 % G == 0, "one digit per thread; whole units per wave instruction");
     __shared__ S sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const u32 w = blockIdx.x;
@@ -392,10 +418,18 @@ __global__ __launch_bounds__(P0_BLOCK, 1) void stream_pass0_kernel(P0Args a) {
     const u64 mask = ~0ull >> (64 - 2 * K);
     const u32 mlo = (u32)mask, mhi = (u32)(mask >> 32);
     const u32 dmask = radix - 1u;
-    if (tid < RADIX) {
-        sm.cnt[tid] = 0; sm.tail[tid] = 0; sm.offlen[tid] = 0;
-        sm.gcur[tid] = (u32)tid < radix ? a.offs[(u64)w * radix + tid] : 0ull;
-    }
+    const u32 nchunks = (u32)((a.n_bytes + 15) >> 4);
+    auto digit = [&](u64 k) -> u32 {
+        if constexpr (FAST) return __builtin_amdgcn_ubfe((u32)(k >> 32), (u32)a.shift - 32u, (u32)a.bits);
+        else return (u32)(k >> a.shift) & dmask;
+    };
+    // this thread's digit
+    u64 F = (u32)tid < radix ? a.offs[(u64)w * radix + tid] : 0ull;          // its next output index
+    const u64 Fend = F + ((u32)tid < radix ? a.rows[(u64)w * radix + tid] : 0u);       // ... where its piece ends
+    u32 nck = 0, ctail = 0;                                                  // keys left over from the last tile, where they sit in exch
+    u32 bad = 0;                                                             // more keys of the digit than the histogram had counted
+    u32 flen_dbg = 0;
+    sm.cnt[tid] = 0;
     // this thread's windows inside a tile: NW consecutive ones from tile position p0 on
     u32 p0 = (u32)NW * tid, wlim = (1u << NW) - 1u;          // wlim: which of them exist at all
     if (a.by_record) {
@@ -407,30 +441,74 @@ __global__ __launch_bounds__(P0_BLOCK, 1) void stream_pass0_kernel(P0Args a) {
     }
     // The image of tile t + 1 is made, and the bytes of tile t + 2 are asked for, BEFORE the stores of tile t are issued: a wait for
     // loaded bytes then never has this tile's stores in front of it (the memory counter is one for loads and stores).
-    uint4 q = make_uint4(0, 0, 0, 0);
-    if ((u32)tid < nch) {
-        q = load_chunk16(a.stream, a.n_bytes, B + 16ull * tid);
-        u32 cc, vv;
-        encode_swar16(q, cc, vv);
-        sm.codes[0][tid] = cc; sm.valid[0][tid] = vv;
-        if (ntile > 1) q = load_chunk16(a.stream, a.n_bytes, B + tile_bytes + 16ull * tid);
-    }
+    u32 qc = 0, qv = 0;
+    auto fetch = [&](u64 T) {          // chunk tid of the tile that starts at stream byte T (a multiple of 16)
+        const u64 idx = (T >> 4) + (u32)tid;
+        const bool in = (u32)tid < nch && idx < nchunks;
+        qc = in ? a.gcodes[idx] : 0u;
+        qv = in ? (u32)a.gvalid[idx] : 0u;
+    };
+    fetch(B);
+    if ((u32)tid < nch) { sm.codes[tid] = qc; sm.valid[tid] = qv; }
+    if (ntile > 1) fetch(B + tile_bytes);
     __syncthreads();
-    u64 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    u64 tlast = a.dbg ? __builtin_amdgcn_s_memtime() : 0;
+    u32 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u32 tlast = a.dbg ? (u32)__builtin_amdgcn_s_memtime() : 0;
+    // Units [first, end) of the list out: G / 2 lanes per unit, two keys (16 bytes) per lane, four units of a lane group in flight
+    // (their LDS reads are issued together; the values are pinned or the compiler moves each unit's reads back under its own branch).
+    struct __attribute__((packed, aligned(8))) Key2 { u64 a, b; };
+    auto store_units = [&](u32 first, u32 end, auto nf) {
+        constexpr int NF = decltype(nf)::value;          // units of a lane group in flight
+        constexpr u32 LPU = G / 2, GROUPS = BLOCK / LPU;
+        const u32 j = 2u * ((u32)tid & (LPU - 1)), g0 = (u32)tid / LPU;
+        for (u32 base = first; base < end; base += NF * GROUPS) {
+            u32 e4[NF];
+            u64 k4[NF], l4[NF], b4[NF];
+#pragma unroll
+            for (int g = 0; g < NF; g++) {
+                const u32 u = base + g * GROUPS + g0;
+                e4[g] = sm.units[u < (u32)S::UNITS ? u : 0u];
+            }
+#pragma unroll
+            for (int g = 0; g < NF; g++) asm volatile("" : "+v"(e4[g]));
+#pragma unroll
+            for (int g = 0; g < NF; g++) {
+                k4[g] = sm.exch[(e4[g] & 0x3fffu) + j];
+                l4[g] = sm.exch[(e4[g] & 0x3fffu) + j + 1];
+                b4[g] = sm.gbase[(e4[g] >> 18) & (u32)(RADIX - 1)];
+            }
+#pragma unroll
+            for (int g = 0; g < NF; g++) asm volatile("" : "+v"(k4[g]), "+v"(l4[g]), "+v"(b4[g]));
+#pragma unroll
+            for (int g = 0; g < NF; g++) {
+                const u32 u = base + g * GROUPS + g0;
+                const u32 len1 = (e4[g] >> 14) & 15u;          // keys - 1
+                u64* dst = a.kout + (b4[g] + (e4[g] & 0x3fffu) + j);          // (inside the digit's piece by construction)
+                if (u < end && a.dbg_mode != 1) {
+                    if (j < len1) { Key2 v; v.a = k4[g]; v.b = l4[g]; *reinterpret_cast<Key2*>(dst) = v; }
+                    else if (j == len1) *dst = k4[g];
+                }
+            }
+        }
+    };
+    u32 held = 0, held_end = 0;          // units [held, held_end) of the last tile are still to be stored
     for (u32 t = 0; t < ntile; t++) {
         const u64 T0 = B + (u64)t * tile_bytes;
         const bool last = t + 1 == ntile;
-        const u32* codes = sm.codes[t & 1];
-        const u32* valid = sm.valid[t & 1];
+        if (a.dbg_mode == 2 && t > 1) {
+            // measurement: the first tile's units again, further down the output
+            __syncthreads();
+            sm.gbase[tid] += flen_dbg;
+            __syncthreads();
+        } else {
         // ---- this thread's keys ---------------------------------------------------------------------
         u64 key[NW];
         u32 live;
         {
             const u32 j = p0 >> 4, s = p0 & 15u;
-            const u64 sa = ((u64)codes[j] << 32) | codes[j + 1];
-            const u64 sb = ((u64)codes[j + 2] << 32) | codes[j + 3];
-            u64 v = ((u64)valid[j] << 48) | ((u64)valid[j + 1] << 32) | ((u64)valid[j + 2] << 16) | (u64)valid[j + 3];
+            const u64 sa = ((u64)sm.codes[j] << 32) | sm.codes[j + 1];
+            const u64 sb = ((u64)sm.codes[j + 2] << 32) | sm.codes[j + 3];
+            u64 v = ((u64)sm.valid[j] << 48) | ((u64)sm.valid[j + 1] << 32) | ((u64)sm.valid[j + 2] << 16) | (u64)sm.valid[j + 3];
             v = runs_of_k(v, K);
             // bit i: window i is a k-mer (of this range: windows from E on belong to the next one)
             live = (__brev((u32)((v << s) >> (64 - NW))) >> (32 - NW)) & wlim;
@@ -439,124 +517,132 @@ __global__ __launch_bounds__(P0_BLOCK, 1) void stream_pass0_kernel(P0Args a) {
             ww.init(sa, sb, s, K);
 #pragma unroll
             for (int i = 0; i < NW; i++) {
-                const u64 x = ((u64)(ww.xhi(i) & mhi) << 32) | (ww.xlo(i) & mlo), xb = ((u64)(ww.bhi(i) & mhi) << 32) | (ww.blo(i) & mlo);
-                key[i] = (a.mode == ZK_KEYS_CANONICAL) ? (x < xb ? x : xb) : x;
+                const u64 x = ((u64)(ww.xhi(i) & mhi) << 32) | (FAST ? ww.xlo(i) : (ww.xlo(i) & mlo));
+                if constexpr (CANON) {
+                    const u64 xb = ((u64)(ww.bhi(i) & mhi) << 32) | (FAST ? ww.blo(i) : (ww.blo(i) & mlo));
+                    key[i] = x < xb ? x : xb;
+                } else key[i] = x;
             }
         }
         // ---- what the last tile left of this thread's digit: into registers, the park below moves it ----------
+        // (every LDS access below is unconditional -- a dead window goes to a slot / a counter of its lane's own: under a branch
+        // per window the accesses run one after the other, each a full LDS round trip)
         u64 ck[G - 1];
-        u32 nck = 0;
-        if (tid < RADIX) {
-            // (the count comes from `tail`, not from cnt: the ranking of this tile is already adding to cnt)
-            const u32 tl = sm.tail[tid];
-            nck = tl >> 16;
-            const u32 at = tl & 0xffffu;
 #pragma unroll
-            for (int j = 0; j < G - 1; j++) ck[j] = (u32)j < nck ? sm.exch[at + j] : 0ull;
-        }
+        for (int j = 0; j < G - 1; j++) ck[j] = sm.exch[ctail + j];          // ctail + j < CAP + G: inside exch
         // ---- rank: the digit's counter hands out the places (no order to keep) ------------------------------
         u32 rk[NW];
 #pragma unroll
         for (int i = 0; i < NW; i++) {
-            const u32 d = (u32)(key[i] >> a.shift) & dmask;
-            rk[i] = ((live >> i) & 1u) ? atomicAdd(&sm.cnt[d], 1u) : 0u;
+            rk[i] = atomicAdd(&sm.cnt[((live >> i) & 1u) ? digit(key[i]) : (u32)RADIX + (u32)lane], 1u);
         }
-        P0_PHASE(0);          // keys made, ranks asked for
+        if (held < held_end) store_units(held, held_end, std::integral_constant<int, 2>());          // (the tile's keys and ranks are live here: two in flight)
+        held = held_end = 0;
+        P0_PHASE(0);          // keys made, ranks asked for (and the second half of the last tile's units out)
         __syncthreads();
         P0_PHASE(1);          // ... waiting for the other waves
         // ---- per digit: how many keys leave now, where the digit sits in LDS --------------------------------
-        u32 tot = 0, flen = 0, front = 0, size = 0;
-        u64 F = 0;
-        if (tid < RADIX) {
+        // Every wave adds up all the counters by itself (lane l: digits 8 l .. 8 l + 7), so that no wave waits for another's sum.
+        u32 O, tot, flen, head, nu;
+        {
+            const uint4 c0 = reinterpret_cast<const uint4*>(sm.cnt)[2 * lane], c1 = reinterpret_cast<const uint4*>(sm.cnt)[2 * lane + 1];
+            const u32 s8 = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
+            const u32 inc8 = wave_incl_scan_dpp(s8);
+            const u32 before = wave ? (u32)__builtin_amdgcn_readlane((int)inc8, 8 * wave - 1) : 0u;          // digits below 64 * wave
             tot = sm.cnt[tid];
-            F = sm.gcur[tid];
-            const u64 end = F + tot;
+            const u32 inc = wave_incl_scan_dpp(tot);
+            O = before + inc - tot;
+            u64 end = F + tot;
+            if (end > Fend) { bad = 1; end = Fend > F ? Fend : F; }          // never beyond the digit's piece (then the error word is set)
             u64 Eo = last ? end : (end & ~(u64)(G - 1));
             if (Eo < F) Eo = F;
             flen = (u32)(Eo - F);
-            front = ALIGN ? (u32)(F & (G - 1)) : 0u;          // slots skipped so that output units are units of slots as well
-            size = ALIGN ? ((front + tot + G - 1) & ~(u32)(G - 1)) : tot;
+            // the keys that leave, cut at the output's grid: a head up to the first grid line (only until the digit is on the grid),
+            // whole units, and on the range's last tile a short tail
+            head = (u32)(F & (G - 1)) ? G - (u32)(F & (G - 1)) : 0u;
+            if (head > flen) head = flen;
+            nu = (head ? 1u : 0u) + (flen - head + G - 1) / G;
+            sm.nu[tid] = (u16)nu;
         }
-        const u32 inc = wave_incl_scan_u32(size);
-        if (lane == 63) sm.wsum[wave] = inc;
-        __syncthreads();
-        u32 woff = 0;
-        for (int q2 = 0; q2 < wave; q2++) woff += sm.wsum[q2];
-        const u32 A = woff + inc - size;          // where the digit's region starts
-        if (tid == BLOCK - 1) sm.total = woff + inc;
-        if (tid < RADIX) {
-            const u32 O = A + front;
-            sm.offlen[tid] = (flen << 16) | O;
-            sm.gbase[tid] = F - O;
-            sm.gcur[tid] = F + flen;
+        __syncthreads();          // every wave has read the counters; the unit counts are there
+        {
+            const uint4 c0 = reinterpret_cast<const uint4*>(sm.nu)[lane];          // eight 16-bit counts: digits 8 l .. 8 l + 7
+            const u32 s2 = c0.x + c0.y + c0.z + c0.w;                             // two sums side by side (each < 2^16)
+            const u32 s8 = (s2 & 0xffffu) + (s2 >> 16);
+            const u32 inc8 = wave_incl_scan_dpp(s8);
+            const u32 before = wave ? (u32)__builtin_amdgcn_readlane((int)inc8, 8 * wave - 1) : 0u;
+            const u32 inc = wave_incl_scan_dpp(nu);
+            u32 U = before + inc - nu;
+            if (tid == 0) sm.nunits = (u32)__builtin_amdgcn_readlane((int)inc8, 63);
+            sm.off[tid] = (u16)O;
             sm.cnt[tid] = tot - flen;
-            sm.tail[tid] = ((tot - flen) << 16) | (O + flen);
+            sm.gbase[tid] = F - O;
+            flen_dbg = flen;
+            // this digit's units
+            u32 slot = O, left = flen;
+            if (head) { sm.units[U++] = unit_pack(slot, head, (u32)tid); slot += head; left -= head; }
+            while (left) {
+                const u32 len = left < (u32)G ? left : (u32)G;
+                sm.units[U++] = unit_pack(slot, len, (u32)tid);
+                slot += len; left -= len;
+            }
+            F += flen;
         }
         __syncthreads();
         P0_PHASE(2);          // scan over the digits (two barriers)
         // ---- park ----------------------------------------------------------------------------------
+        {
+            u32 at[NW];
 #pragma unroll
-        for (int i = 0; i < NW; i++) {
-            const u32 d = (u32)(key[i] >> a.shift) & dmask;
-            if ((live >> i) & 1u) sm.exch[(sm.offlen[d] & 0xffffu) + rk[i]] = key[i];
-        }
-        if (tid < RADIX) {
-            const u32 O = A + front;
+            for (int i = 0; i < NW; i++) at[i] = sm.off[digit(key[i])];
 #pragma unroll
-            for (int j = 0; j < G - 1; j++) if ((u32)j < nck) sm.exch[O + j] = ck[j];
-            if (ALIGN) {
-                // the slots of the region that hold no key get one of this digit that is never stored (outside [O, O + flen))
-                const u64 fill = (u64)tid << a.shift;
-                for (u32 j = 0; j < front; j++) sm.exch[A + j] = fill;
-                for (u32 j = O + tot; j < A + size; j++) sm.exch[j] = fill;
-            }
+            for (int i = 0; i < NW; i++) sm.exch[((live >> i) & 1u) ? at[i] + rk[i] : (u32)S::CAP + (u32)lane] = key[i];
+#pragma unroll
+            for (int j = 0; j < G - 1; j++) sm.exch[(u32)j < nck ? O + j : (u32)S::CAP + (u32)lane] = ck[j];
+            nck = tot - flen;
+            ctail = O + flen;
         }
         P0_PHASE(3);          // parked
         __syncthreads();
         P0_PHASE(4);          // ... waiting
         // ---- the next tile's image; the bytes of the tile after it ------------------------------------------
-        if (!last && (u32)tid < nch) {
-            u32 cc, vv;
-            encode_swar16(q, cc, vv);
-            sm.codes[(t + 1) & 1][tid] = cc; sm.valid[(t + 1) & 1][tid] = vv;
-            if (t + 2 < ntile) q = load_chunk16(a.stream, a.n_bytes, T0 + 2ull * tile_bytes + 16ull * tid);
+        if (!last) {
+            if ((u32)tid < nch) { sm.codes[tid] = qc; sm.valid[tid] = qv; }          // (this tile's image is dead since its keys were made)
+            if (t + 2 < ntile) fetch(T0 + 2ull * tile_bytes);
         }
         P0_PHASE(5);          // next image (includes the wait for its bytes)
-        // ---- whole units out ----------------------------------------------------------------------------
-        const u32 total = sm.total;
-#pragma unroll 4
-        for (u32 p = (u32)tid; p < total; p += BLOCK) {
-            const u64 k = sm.exch[p];
-            const u32 d = (u32)(k >> a.shift) & dmask;
-            const u32 ol = sm.offlen[d];
-            if (p - (ol & 0xffffu) < (ol >> 16)) {
-                const u64 pos = sm.gbase[d] + p;
-                if (pos < a.n) a.kout[pos] = k; else atomicOr(a.err, ZK_DERR_MISMATCH);
-            }
+        }
+        // ---- whole units out: the first half now, the second after the next tile's keys are made (what they read stays as it is
+        // until that tile's scan and park): two bursts of stores per tile instead of one, the other workgroup of the CU fills the gaps
+        {
+            const u32 nunits = sm.nunits;
+            const u32 half = (a.dbg_mode == 2 || !a.split_stores) ? nunits : (nunits / 2 + 127u) & ~127u;
+            store_units(0, half < nunits ? half : nunits, std::integral_constant<int, 4>());
+            held = half < nunits ? half : nunits; held_end = nunits;
         }
         P0_PHASE(6);          // stores issued
         __syncthreads();          // the next image is whole; nobody still reads what the next tile's scan and park rewrite
         P0_PHASE(7);          // ... waiting
     }
+    if (held < held_end) store_units(held, held_end, std::integral_constant<int, 2>());
     if (a.dbg && tid == 0) {
-        for (int k = 0; k < 8; k++) a.dbg[(u64)w * 16 + k] = ph[k];
+        for (int k = 0; k < 8; k++) a.dbg[(u64)w * 16 + k] = (u64)ph[k];
         a.dbg[(u64)w * 16 + 8] = ntile;
     }
-    __syncthreads();
-    if ((u32)tid < radix && (sm.gcur[tid] != a.offs[(u64)w * radix + tid] + a.rows[(u64)w * radix + tid] || sm.cnt[tid] != 0))
-        atomicOr(a.err, ZK_DERR_MISMATCH);
+    if (a.dbg_mode) return;
+    if (bad || ((u32)tid < radix && (F != Fend || nck != 0))) atomicOr(a.err, ZK_DERR_MISMATCH);
 }
 
 // ---------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------
-int stream_ranges(zk_ctx* c) { return c->stream_ranges > 0 ? c->stream_ranges : (c->num_cus > 0 ? c->num_cus : 1); }
+int stream_ranges(zk_ctx* c) { return c->stream_ranges > 0 ? c->stream_ranges : 2 * (c->num_cus > 0 ? c->num_cus : 1); }
 
 // histogram of every pass's digit + acgt + the uniformity check + (optionally) the set-aside blocks, and pass 0's digit counts per
 // range.  ghist: [MAX_PASSES][gstride] (zeroed here; exclusive prefixes on return, the key count in *d_n).
 int stream_hist(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, const PassPlan& plan, u64* ghist, u32 gstride,
                 u64* d_acgt, u64* d_n, u64* rec_info, u64* sample, u32 sample_cap, int sample_shift, u64 sample_value, u32* sample_n,
-                StreamRows* out) {
+                void* image_room, uint64_t image_room_bytes, StreamRows* out) {
     SHistArgs h = {};
     h.stream = stream; h.n_bytes = n_bytes; h.K = K; h.mode = mode; h.plan = plan;
     u32 nb = 0;
@@ -568,11 +654,19 @@ int stream_hist(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, 
     h.acgt = d_acgt; h.rec_info = rec_info;
     h.sample = sample; h.sample_n = sample_n; h.sample_cap = sample_cap; h.sample_shift = sample_shift; h.sample_value = sample_value;
     h.ranges = (u32)stream_ranges(c);
-    h.split = 8;
+    h.split = 4;
     const u32 r0 = 1u << plan.bits[0];
+    const uint64_t nchunks = (n_bytes + 15) / 16;
     u32* rows; u64* offs;
     ZK_TRY(arena_alloc(c, sizeof(u32) * (uint64_t)h.ranges * r0, (void**)&rows));
     ZK_TRY(arena_alloc(c, sizeof(u64) * (uint64_t)h.ranges * r0, (void**)&offs));
+    // the stream's 2-bit image (3/8 of the stream's size): in the room the caller has for it (the tail of the second sort buffer, idle
+    // until pass 1), else from the arena
+    const uint64_t codes_bytes = (sizeof(u32) * nchunks + 255) & ~255ull, image_bytes = codes_bytes + ((sizeof(u16) * nchunks + 255) & ~255ull);
+    char* img = nullptr;
+    if (image_room && image_room_bytes >= image_bytes + 256) img = (char*)(((uintptr_t)image_room + image_room_bytes - image_bytes) & ~(uintptr_t)255);
+    else ZK_TRY(arena_alloc(c, image_bytes, (void**)&img));
+    h.gcodes = (u32*)img; h.gvalid = (u16*)(img + codes_bytes);
     h.rows = rows;
     ZK_HIP(c, hipMemsetAsync(rows, 0, sizeof(u32) * (uint64_t)h.ranges * r0, c->stream));
     ZK_HIP(c, hipMemsetAsync(ghist, 0, sizeof(u64) * MAX_PASSES * gstride, c->stream));
@@ -586,25 +680,26 @@ int stream_hist(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, 
     else hipLaunchKernelGGL((stream_hist_kernel<false, false>), dim3(grid), dim3(SH_BLOCK), nb * sizeof(u32), c->stream, h);
     prof_end(c);
     ZK_HIP(c, hipGetLastError());
-    out->rows = rows; out->offs = offs; out->ranges = h.ranges; out->radix = r0;
+    out->rows = rows; out->offs = offs; out->ranges = h.ranges; out->radix = r0; out->gcodes = h.gcodes; out->gvalid = h.gvalid;
     return ZK_OK;
 }
 
 // after the exclusive prefix of pass 0's digits is in ghist0 and the host has read the verdict on the records
-int stream_pass0(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, int shift, int bits, const u64* ghist0, const StreamRows& rows,
+int stream_pass0(zk_ctx* c, uint64_t n_bytes, int K, int mode, int shift, int bits, const u64* ghist0, const StreamRows& rows,
                  uint64_t first_nl, bool uniform, u64* kout, uint64_t n, int variant) {
-    if (bits < 1 || (1u << bits) != rows.radix) return fail(c, ZK_EINTERNAL, "stream_pass0: %d digit bits, rows of %u", bits, rows.radix);
+    if (bits < 1 || bits > 9 || (1u << bits) != rows.radix) return fail(c, ZK_EINTERNAL, "stream_pass0: %d digit bits, rows of %u", bits, rows.radix);
     hipLaunchKernelGGL(rows_scan_kernel, dim3((rows.radix + 255) / 256), dim3(256), 0, c->stream, rows.rows, ghist0, rows.ranges, rows.radix, rows.offs);
     P0Args a = {};
-    a.stream = stream; a.n_bytes = n_bytes; a.K = K; a.mode = mode;
+    a.gcodes = rows.gcodes; a.gvalid = rows.gvalid; a.n_bytes = n_bytes; a.K = K;
     a.tl = make_tiling(n_bytes, first_nl, K, rows.ranges);
     a.by_record = (uniform && a.tl.rec) ? 1 : 0;
-    a.shift = shift; a.bits = bits; a.offs = rows.offs; a.rows = rows.rows; a.kout = kout; a.n = n; a.err = c->d_err; a.dbg = c->dbg;
+    a.shift = shift; a.bits = bits; a.offs = rows.offs; a.rows = rows.rows; a.kout = kout; a.n = n; a.err = c->d_err; a.dbg = c->dbg; a.dbg_mode = variant >> 8; a.split_stores = (variant & 0xff) == 3;          // measured: 10.05 vs 8.73 ms on 20 M reads -- the held-back half sits in the key phase's way
+    const bool canon = mode == ZK_KEYS_CANONICAL, fast = 2 * K > 32 && shift >= 32;
     prof_begin(c, ZK_PROF_PASS_STREAM, n_bytes + 8 * n);
-    if (bits <= 9 && variant == 2) hipLaunchKernelGGL((stream_pass0_kernel<9, 16, false>), dim3(rows.ranges), dim3(P0_BLOCK), 0, c->stream, a);
-    else if (bits <= 9 && variant == 3) hipLaunchKernelGGL((stream_pass0_kernel<9, 8, false>), dim3(rows.ranges), dim3(P0_BLOCK), 0, c->stream, a);
-    else if (bits <= 9) hipLaunchKernelGGL((stream_pass0_kernel<9, 8, true>), dim3(rows.ranges), dim3(P0_BLOCK), 0, c->stream, a);
-    else return fail(c, ZK_EINTERNAL, "stream_pass0: %d digit bits", bits);
+    if (canon && fast) hipLaunchKernelGGL((stream_pass0_kernel<9, 8, true, true>), dim3(rows.ranges), dim3(P0_BLOCK), 0, c->stream, a);
+    else if (canon) hipLaunchKernelGGL((stream_pass0_kernel<9, 8, true, false>), dim3(rows.ranges), dim3(P0_BLOCK), 0, c->stream, a);
+    else if (fast) hipLaunchKernelGGL((stream_pass0_kernel<9, 8, false, true>), dim3(rows.ranges), dim3(P0_BLOCK), 0, c->stream, a);
+    else hipLaunchKernelGGL((stream_pass0_kernel<9, 8, false, false>), dim3(rows.ranges), dim3(P0_BLOCK), 0, c->stream, a);
     prof_end(c);
     ZK_HIP(c, hipGetLastError());
     return ZK_OK;
