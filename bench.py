@@ -13,15 +13,18 @@ is BASELINE config 2 (50 M x 150 bp genome-sampled reads, K = 25).  At N > 1 eve
 RCCL all-to-all and union-summed, so that each rank ends up owning one piece of the global table.
 
 `value` counts emitted k-mer instances (both strands, the unit the reference counts at commands/kmerize.py:523-525) per
-second of wall time over the timed steps.  `roofline` is the dominant kernel (one radix-sort pass over the key array):
-algorithmic 16 B/key over its mean launch time, measured with HIP events on the library's own stream.  The result of
-the last timed step is verified outside the timed region (order-free checksums of the table against the same sums taken
-straight from the base stream; `verified_checksums`).  `cpu_baseline`: the C oracle on one core on a prefix of the same
+second of wall time over the timed steps.  `roofline` is whichever of the two full-size sort kernels takes more of a step
+-- the array pass (16 B/key) or pass 0 from the base stream (1 B/stream byte + 8 B/key) -- its algorithmic bytes over its
+mean launch time by HIP events on the library's own stream, the other listed beside it; `peak` is the 8 TB/s of the spec,
+`peak_measured` what a device-to-device copy reaches on this box in this run.  The result of the last timed step is
+verified outside the timed region: order-free checksums of the table against the same sums taken straight from the base
+stream by an independent encoder, and strict ascent of the k-mers (`verified_checksums`, `verified_ascending`).  `cpu_baseline`: the C oracle on one core on a prefix of the same
 reads, and the pure-Python restatement of the reference path on BASELINE config 1.
 
 `extra` (N = 1): config 3 (`zot dist` on two 100 M-k-mer sets), one GPU's share of config 4 (merge of 8 x 50 M-k-mer
-sets), one GPU's share of config 5 (K = 31, 37.5 M reads) and config 2 again with the base stream starting in pinned
-host memory (H2D inside the timed region).  N > 1: `zot merge` (8 sets per GPU, config 4 at N = 8) and `zot dist`
+sets), one GPU's share of config 5 (K = 31, 37.5 M reads), config 2 again with the base stream starting in pinned
+host memory (H2D inside the timed region), and the two inputs the headline does not cover: reads without repeats
+(SURVEY 8(d)'s uniform workload) and reads of varying length.  N > 1: `zot merge` (8 sets per GPU, config 4 at N = 8) and `zot dist`
 (config 3 sharded over the GPUs) through the product functions of zotmer_amd/parallel.py.  Every block is verified.
 """
 import argparse
@@ -80,6 +83,25 @@ def measured_traffic(kernel_substr, n_keys_now):
     return best
 
 
+def measured_step_traffic(n_keys_now):
+    """HBM bytes of a whole step (all kernels) from the newest committed PMC profile of these kernel sources, or None"""
+    prof = os.path.join(ROOT, "profiles")
+    best = None
+    for sub in sorted(os.listdir(prof)) if os.path.isdir(prof) else []:
+        path = os.path.join(prof, sub, "pmc_traffic.json")
+        if os.path.exists(path):
+            try:
+                d = json.load(open(path))
+            except Exception:
+                continue
+            if d.get("_kernel_source_sha256") != kernel_source_hash() or "_traffic_bytes_per_step" not in d:
+                continue
+            keys = [v.get("n_keys") for v in d.values() if isinstance(v, dict) and v.get("n_keys")]
+            if keys and abs(keys[0] - n_keys_now) <= 0.001 * max(n_keys_now, 1):
+                best = dict(bytes=d["_traffic_bytes_per_step"], profile="sum over all kernels of a step, profiles/%s/pmc_traffic.json" % sub)
+    return best
+
+
 def cpu_baseline(cfg, seed, budget_s=12.0):
     """(a) single-core C oracle on a prefix of the same reads, sized to about budget_s seconds; (b) the pure-Python
     restatement of the reference path on BASELINE config 1."""
@@ -131,6 +153,54 @@ def timed(ctx, fn, steps, warmup=1):
     kern = {n: dict(launches=v["launches"] // steps, ms_per_step=v["ms"] / steps, GBps=(v["bytes"] / 1e9) / (v["ms"] / 1e3) if v["ms"] else None)
             for n, v in prof.items()}
     return dt, r, kern
+
+
+def copy_peak(ctx, nbytes=4 << 30, reps=5):
+    """what a device-to-device copy reaches here (read + written bytes per second), GB/s"""
+    a, b = ctx.empty(nbytes, np.uint8), ctx.empty(nbytes, np.uint8)
+    best = 0.0
+    for _ in range(reps):
+        ctx.sync()
+        t0 = time.perf_counter()
+        ctx._check(ctx.lib.zk_copy(ctx.h, b.ptr, a.ptr, nbytes))
+        ctx.sync()
+        best = max(best, 2 * nbytes / (time.perf_counter() - t0) / 1e9)
+    del a, b
+    return best
+
+
+def kernel_table(prof, steps):
+    """per-kernel time and algorithmic rate of one step, from the library's HIP-event records"""
+    return {n: dict(launches=v["launches"] // steps, ms_per_step=v["ms"] / steps,
+                    GBps=(v["bytes"] / 1e9) / (v["ms"] / 1e3) if v["ms"] else None,
+                    frac_of_peak=(v["bytes"] / 1e9) / (v["ms"] / 1e3) / HBM_PEAK_GBS if v["ms"] else None)
+            for n, v in prof.items()}
+
+
+def extra_kmerize_variant(ctx, name, stream, K, steps, note, cap):
+    """zk_kmerize + zk_hist on another kind of input, verified the same way as the headline (cap: entries the table may have)"""
+    out_k, out_c = ctx.empty(cap, np.uint64), ctx.empty(cap, np.uint32)
+
+    def step():
+        k, c, st = ctx.kmerize(stream, K, 0, out=(out_k, out_c))
+        return k, c, st, ctx.hist(c)
+
+    step()
+    ctx.sync()
+    ctx.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        k, c, st, h = step()
+    ctx.sync()
+    dt = (time.perf_counter() - t0) / steps
+    prof = ctx.profile_read()
+    ctx.profile(False)
+    ok = ctx.checksum(k, c) == ctx.stream_checksum(stream, K)
+    asc = ctx.first_descent(k) == k.n
+    return {"workload": note, "value": st.n_instances / dt / 1e9, "unit": "Gk-mers/s", "ms_per_step": dt * 1e3,
+            "instances_per_step": st.n_instances, "unique": st.n_unique, "canonical_unique": st.n_canonical,
+            "verified": bool(ok and asc), "verified_by": "order-free checksums against the independent stream encoder + strict ascent of the k-mers",
+            "kernels": kernel_table(prof, steps)}
 
 
 def add_sums(a, b):
@@ -250,7 +320,7 @@ def extra_config5_share(ctx, scale, synth, seed, batches=4):
         if attempt == 0:
             want0 = want
     inst = table.instances
-    ok = ctx.checksum(k, c) == want0 and inst == want0[0]
+    ok = ctx.checksum(k, c) == want0 and inst == want0[0] and ctx.first_descent(k) == k.n
     n_unique = k.n
     mb = model_bytes(R5 * (L + 1), inst, n_unique, K)
     slab_bytes = 12 * (table.slab.E + table.scratch.E)
@@ -263,8 +333,10 @@ def extra_config5_share(ctx, scale, synth, seed, batches=4):
                         % (K, R5, L, c5["genome"], batches),
             "value": inst / t / 1e9, "unit": "Gk-mers/s", "ms_total": t * 1e3, "cold_ms": runs[0] * 1e3, "table_slab_bytes": slab_bytes,
             "instances": inst, "unique": n_unique,
-            "verified": bool(ok), "verified_by": "order-free checksums of the final table == the sums taken from the base streams of all batches",
-            "roofline": {"bound": "hbm", "model_bytes": mb, "model_frac_of_peak": mb / t / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
+            "verified": bool(ok), "verified_by": "order-free checksums of the final table == the sums taken from the base streams of all batches; "
+                                                 "k-mers strictly ascending",
+            "roofline": {"bound": "hbm", "model_bytes": mb, "speedup_over_unfused_model_at_peak": mb / t / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s"}}
 
 
 def extra_e2e_h2d(ctx, stream, K, steps, out_k, out_c):
@@ -505,13 +577,18 @@ def main():
     else:
         total_instances = st.n_instances
 
-    verify = None
+    verify, ascending = None, None
     if not a.no_verify:
         want = ctx.stream_checksum(stream, K)
         if par is None:
             verify = bool(ctx.checksum(k, c) == want)
         else:
             verify = bool(par.verify_global(k, c, want))
+        # the checksums are order-free: the order is checked apart (every rank's piece strictly ascending)
+        ascending = bool(ctx.first_descent(k) == k.n)
+        if par is not None:
+            ascending = bool(par.comm.all_reduce([0 if ascending else 1])[0] == 0)
+    peak_measured = copy_peak(ctx) if rank == 0 and not a.no_verify else None          # (not in profiled runs)
 
     extras = {}
     if not a.no_extras:
@@ -525,8 +602,41 @@ def main():
                     extras[name] = fn()
                 except Exception as e:      # an extra never takes the headline down; the failure is in the line
                     extras[name] = {"error": repr(e)}
-            del stream, out_k, out_c
-            stream = out_k = out_c = None
+            del out_k, out_c
+            out_k = out_c = None
+            # the inputs the headline does not cover
+            try:
+                # reads of varying length: every record of config 2 cut in two at a place between its bases 100 and 149
+                # (a newline replaces that base), so no two neighbouring records have the same length and the tiles of the
+                # first pass follow positions, not records
+                R2 = int(R * sc)
+                host = stream.to_host(R2 * (L + 1))
+                i = np.arange(R2, dtype=np.uint64)
+                host[(i * np.uint64(L + 1) + np.uint64(100) + (synth.mix64(i + np.uint64(seed)) % np.uint64(50))).astype(np.int64)] = 10
+                var = ctx.upload(host)
+                del host, i
+                extras["config2_variable_length"] = extra_kmerize_variant(
+                    ctx, "var", var, K, 2, "BASELINE config 2 with every record cut in two at a varying place (%d records of 0 .. 149 bases, "
+                    "%d stream bytes): tiles of positions, same pipeline" % (2 * R2, var.n), cap)
+                del var
+            except Exception as e:
+                extras["config2_variable_length"] = {"error": repr(e)}
+            del stream
+            stream = None
+            ctx.release_workspace()
+            try:
+                # SURVEY 8(d)'s secondary workload, "worst case U ~ I": iid bases, no k-mer repeats -- the look before the sort declines
+                # the top-bits-first plan and every key goes through all six passes.  20 M reads: the table of 50 M such reads
+                # (12.6 G entries) and the sort buffers together exceed the card.
+                Ru = int(20_000_000 * sc)
+                uni = ctx.synth_reads(seed + 1, 0, Ru, L, genome=0, sub_thr=0, n_thr=synth.frac32(cfg["n"]))
+                extras["uniform_reads"] = extra_kmerize_variant(
+                    ctx, "uniform", uni, K, 2, "SURVEY 8(d) uniform workload: zot kmerize k=%d on %d x %d bp reads of iid bases (no k-mer occurs twice): "
+                    "the plain six-pass plan" % (K, Ru, L), 2 * Ru * (L - K + 1) + 1024)
+                del uni
+            except Exception as e:
+                extras["uniform_reads"] = {"error": repr(e)}
+            ctx.release_workspace()
             try:
                 extras["config5_share_k31"] = extra_config5_share(ctx, sc, synth, seed)
             except Exception as e:
@@ -546,14 +656,16 @@ def main():
         # array pass runs once per step and the pass that reads the base stream is its equal); the other is listed beside it
         cands = {"pass_keys": ("pass_pipe_kernel<array,keys> (one LSD radix pass of 64-bit keys, 16 B/key, persistent two-stage pipeline)",
                                "pass_pipe_kernel<zk::Cfg<512, 16, 9, 1, 4, 32, true>, 0, 0>"),
-                 "pass_stream": ("pass_pipe_kernel<stream> (pass 0: base stream -> canonical 64-bit keys, ranked and scattered; 1 B/stream byte + 8 B/key)",
-                                 "pass_pipe_kernel<zk::Cfg<512, 16, 9, 1, 4, 32, true>, 1, 0>")}
+                 "pass_stream": ("stream_pass0_kernel (pass 0 over static stream ranges: 2-bit image -> canonical 64-bit keys, grouped by digit in LDS, "
+                                 "whole 64-byte units out; 1 B/stream byte + 8 B/key)",
+                                 "stream_pass0_kernel<9, 8, true, true>")}
         empty = dict(launches=0, ms=0.0, bytes=0)
         dom = max(cands, key=lambda n: prof.get(n, empty)["ms"])
         pk = prof.get(dom, empty)
         ach = (pk["bytes"] / 1e9) / (pk["ms"] / 1e3) if pk["ms"] else 0.0
         mb = model_bytes(n_bytes, st.n_instances, st.n_unique, K)
         traffic = measured_traffic(cands[dom][1], st.n_windows)
+        step_traffic = measured_step_traffic(st.n_windows)
         others = []
         for n in cands:
             v = prof.get(n, empty)
@@ -576,6 +688,9 @@ def main():
                                       % (world, par.owner, par.comm.name)},
             "roofline": {"bound": "hbm", "kernel": cands[dom][0],
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "peak_measured": peak_measured,
+                         "peak_measured_note": "device-to-device copy of 4 GiB (read + written bytes per second), best of 5, this run",
+                         "frac_of_measured": ach / peak_measured if peak_measured else None,
                          "traffic": traffic["bytes"] if traffic else None,
                          "traffic_note": ("HBM bytes per launch from rocprofv3 PMC (2*FETCH_SIZE + WRITE_SIZE) of this command and these kernel sources, "
                                           + traffic["profile"]) if traffic else
@@ -584,13 +699,18 @@ def main():
                          "avg_launch_ms": pk["ms"] / pk["launches"] if pk["launches"] else None,
                          "others": others},
             "pipeline": {"windows_per_s": value * 1e9 / 2, "instances_per_step": st.n_instances, "unique": st.n_unique,
-                         "canonical_unique": st.n_canonical, "model_bytes": mb,
-                         "model_frac_of_peak": mb / (dt / a.steps) / 1e9 / HBM_PEAK_GBS if world == 1 else None,
-                         "hist_bins": len(h),
-                         "kernels": {n: dict(launches=v["launches"], ms_per_step=v["ms"] / a.steps,
-                                             GBps=(v["bytes"] / 1e9) / (v["ms"] / 1e3) if v["ms"] else None)
-                                     for n, v in prof.items()}},
-            "verified_checksums": verify,
+                         "canonical_unique": st.n_canonical, "hist_bins": len(h),
+                         # what the step really moves (PMC: 2 * FETCH_SIZE + WRITE_SIZE summed over every kernel of a step) over
+                         # the step time: the whole step as a fraction of the HBM peak
+                         "traffic_bytes_per_step": step_traffic["bytes"] if step_traffic else None,
+                         "traffic_frac_of_peak": step_traffic["bytes"] / (dt / a.steps) / 1e9 / HBM_PEAK_GBS if step_traffic and world == 1 else None,
+                         "traffic_note": step_traffic["profile"] if step_traffic else "null: no committed PMC profile of these kernel sources",
+                         # SURVEY 8(d)'s UNFUSED model (both strands through every pass): the build no longer does that work, so this
+                         # ratio is a speed-up over the naive plan at peak bandwidth, NOT a roofline fraction
+                         "model_bytes": mb,
+                         "speedup_over_unfused_model_at_peak": mb / (dt / a.steps) / 1e9 / HBM_PEAK_GBS if world == 1 else None,
+                         "kernels": kernel_table(prof, a.steps)},
+            "verified_checksums": verify, "verified_ascending": ascending,
             "extra": extras,
         }
         if owned is not None:

@@ -327,6 +327,11 @@ int zk_synth_reads(zk_ctx* ctx, uint64_t seed, uint64_t first, uint64_t count, i
  * the full-size parity tests.  d_counts may be NULL (every count 1). */
 int zk_checksum(zk_ctx* ctx, const uint64_t* d_kmers, const uint32_t* d_counts, uint64_t n, uint64_t sums[3]);
 
+/* The sorted-set format stores strictly ascending k-mers (library/files.py:54-110 delta-codes them; every consumer merges on
+ * that order, commands/merge.py:26-86).  *first_bad = the first index i >= 1 with d_kmers[i] <= d_kmers[i - 1], or n if the
+ * array is strictly ascending: the order check of the full-size parity tests (the checksums are order-free). */
+int zk_first_descent(zk_ctx* ctx, const uint64_t* d_kmers, uint64_t n, uint64_t* first_bad);
+
 /* zk_checksum over 32- or 64-bit counts (`zot merge` works on 64-bit counts) */
 int zk_checksum_counts(zk_ctx* ctx, const uint64_t* d_kmers, const void* d_counts, int count_bits, uint64_t n, uint64_t sums[3]);
 

@@ -235,6 +235,33 @@ int zk_hash_partition(zk_ctx* c, const uint64_t* d_kmers, const void* d_counts, 
     return hash_partition(c, (const u64*)d_kmers, d_counts, count_bits, n, world, seed, (u64*)d_ok, d_oc, offsets);
 }
 
+// first index whose key is not above the one before it (n: strictly ascending)
+__global__ void first_descent_kernel(const u64* __restrict__ k, u64 n, u64* out) {
+    u64 best = ~0ull;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x + 1; i < n; i += (u64)gridDim.x * blockDim.x)
+        if (k[i] <= k[i - 1] && i < best) best = i;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const u64 t = __shfl_xor(best, o, 64); best = t < best ? t : best; }
+    if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin((unsigned long long*)out, (unsigned long long)best);
+}
+
+int zk_first_descent(zk_ctx* c, const uint64_t* d_kmers, uint64_t n, uint64_t* first_bad) {
+    if (!c) return ZK_EINVAL;
+    enter(c);
+    if (!first_bad || (n && !d_kmers)) return fail(c, ZK_EINVAL, "zk_first_descent: bad argument");
+    u64* d = c->d_scalars + 12;
+    ZK_HIP(c, hipMemsetAsync(d, 0xff, sizeof(u64), c->stream));
+    if (n > 1) {
+        const u64 g = (n + 255) / 256, mx = (u64)c->num_cus * 16;
+        hipLaunchKernelGGL(first_descent_kernel, dim3((u32)(g < mx ? g : mx)), dim3(256), 0, c->stream, (const u64*)d_kmers, (u64)n, d);
+        ZK_HIP(c, hipGetLastError());
+    }
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 12, d, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    *first_bad = c->h_scalars[12] == ~0ull ? n : c->h_scalars[12];
+    return ZK_OK;
+}
+
 int zk_checksum_counts(zk_ctx* c, const uint64_t* d_kmers, const void* d_counts, int count_bits, uint64_t n, uint64_t sums[3]) {
     if (!c) return ZK_EINVAL;
     enter(c);

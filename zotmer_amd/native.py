@@ -104,6 +104,7 @@ SIGNATURES = {
     "zk_synth_reads": (_i, [_vp, _u64, _u64, _u64, _i, _u64, _u32, _u32, _vp]),
     "zk_checksum": (_i, [_vp, _vp, _vp, _u64, _pu64]),
     "zk_checksum_counts": (_i, [_vp, _vp, _vp, _i, _u64, _pu64]),
+    "zk_first_descent": (_i, [_vp, _vp, _u64, _pu64]),
     "zk_synth_keys": (_i, [_vp, _u64, _u64, _u64, _i, _u64, _u64, _u64, _vp]),
     "zk_synth_counts": (_i, [_vp, _u64, _vp, _u64, _vp]),
     "zk_hash_partition": (_i, [_vp, _vp, _vp, _i, _u64, _i, _u64, _vp, _vp, _pu64]),
@@ -563,6 +564,12 @@ class Context:
         s = (C.c_uint64 * 3)()
         self._check(self.lib.zk_checksum(self.h, kmers.ptr, counts.ptr if counts is not None else None, kmers.n, s))
         return tuple(int(v) for v in s)
+
+    def first_descent(self, kmers):
+        """first index whose k-mer is not above its predecessor; kmers.n if strictly ascending"""
+        r = C.c_uint64(0)
+        self._check(self.lib.zk_first_descent(self.h, kmers.ptr, kmers.n, C.byref(r)))
+        return int(r.value)
 
     def checksum_counts(self, kmers, counts):
         """zk_checksum over 32- or 64-bit counts"""
