@@ -210,7 +210,8 @@ def add_sums(a, b):
 # ---- extra blocks (N = 1) -------------------------------------------------------------------------------------
 def extra_config3(ctx, steps, scale):
     """BASELINE config 3: `zot dist` on two sorted sets of 100 M 50-bit k-mers, half shared.  Timed: Measure.prep on both
-    files (zk_project_dedupe, identity at K = fK but the pass is what the command runs) + dist.split (zk_split).
+    files as the command does it (library/engine.py measure_prep: at K = fK a read-only check of the strict ascent, no copy)
+    + dist.split (zk_split).
     Verified: (a) the generator's construction (two windows of one key sequence overlap in exactly half), (b) an
     independent path -- concatenate, radix sort, run-length count: the number of runs of length 2 is |X & Y|."""
     from zotmer_amd import synth
@@ -218,14 +219,10 @@ def extra_config3(ctx, steps, scale):
     n = int(c3["n"] * scale)
     ka, _ = ctx.synth_set(c3["seed"], 0, n, c3["key_bits"], counts=False)
     kb, _ = ctx.synth_set(c3["seed"], n // 2, n, c3["key_bits"], counts=False)
-    pa, pb = ctx.empty(ka.n, np.uint64), ctx.empty(kb.n, np.uint64)
+    from zotmer_amd.library import engine
 
-    def prep_and_split():
-        import ctypes as C
-        m = C.c_uint64(0)
-        ctx._check(ctx.lib.zk_project_dedupe(ctx.h, ka.ptr, ka.n, 0, pa.ptr, pa.n, C.byref(m)))
-        ctx._check(ctx.lib.zk_project_dedupe(ctx.h, kb.ptr, kb.n, 0, pb.ptr, pb.n, C.byref(m)))
-        return ctx.split(pa, pb)
+    def prep_and_split():          # what the command runs per pair: commands/dist.py prep() on both files, then the split
+        return ctx.split(engine.measure_prep(ctx, ka, 0), engine.measure_prep(ctx, kb, 0))
 
     dt_all, abc, kern_all = timed(ctx, prep_and_split, steps)
     dt, abc2, kern = timed(ctx, lambda: ctx.split(ka, kb), steps)

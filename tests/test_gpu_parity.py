@@ -602,6 +602,29 @@ def test_dist_golden(ctx):
         assert list(ctx.split(x, y)) == t["abc"]
 
 
+def test_first_descent_and_measure_prep(ctx):
+    """zk_first_descent: the first index whose k-mer is not above its predecessor (n if strictly ascending).  Measure.prep of
+    zot dist (commands/dist.py:43-49) at the file's own K uses it to skip the identity copy; a set that repeats a k-mer, or a
+    projection to a shorter K, still goes through zk_project_dedupe."""
+    from zotmer_amd.library import engine
+    rng = np.random.default_rng(5)
+    k = np.unique(rng.integers(0, 1 << 50, size=300000, dtype=np.uint64))
+    d = ctx.upload(k)
+    assert ctx.first_descent(d) == d.n
+    assert ctx.first_descent(ctx.upload(k[:1])) == 1 and ctx.first_descent(d.view(0)) == 0
+    for at in (1, 77777, len(k) - 1):
+        bad = k.copy()
+        bad[at] = bad[at - 1]                               # equal neighbours are a descent too (strict)
+        assert ctx.first_descent(ctx.upload(bad)) == at
+    bad = k.copy()
+    bad[1000], bad[200000] = bad[999] - np.uint64(1), np.uint64(0)
+    assert ctx.first_descent(ctx.upload(bad)) == 1000
+    assert engine.measure_prep(ctx, d, 0) is d             # nothing copied
+    twice = np.sort(np.concatenate([k, k[:50]]))
+    assert np.array_equal(engine.measure_prep(ctx, ctx.upload(twice), 0).to_host(), k)
+    assert np.array_equal(engine.measure_prep(ctx, d, 14).to_host(), np.unique(k >> np.uint64(14)))
+
+
 @pytest.mark.parametrize("nx,ny", [(0, 0), (0, 5), (5, 0), (1, 1), (4096, 4096), (100001, 77), (400000, 380000)])
 def test_split_random_vs_oracle(ctx, nx, ny):
     rng = np.random.default_rng(nx + 3 * ny)

@@ -63,7 +63,7 @@ def main(argv):
             if fK < K:
                 raise MismatchedK(K, fK)
             k = vectors.device_read_kmers(ctx, z)
-        return ctx.project_dedupe(k, 2 * (fK - K))
+        return engine.measure_prep(ctx, k, 2 * (fK - K))
 
     print("\t".join(["lhs.name", "rhs.name"] + ms))
     sets = {}

@@ -372,3 +372,14 @@ def count_fastq_file(ctx, table, path, batch_bytes, take=None):
                 break
             cur = 1 - cur
     return lines // 4
+
+
+def measure_prep(ctx, kmers, shift):
+    """Measure.prep of `zot dist` (commands/dist.py:43-49): xs = uniq(x >> shift).  At shift 0 -- the file's own K, the usual case --
+    that is the identity on a valid set, whose k-mers ascend strictly (library/files.py:54-110): one read-only pass checks
+    exactly that (zk_first_descent: 8 B/k-mer read, nothing written) and the decoded array is used as it is; only a set that
+    breaks the format's invariant, or a projection to a shorter K, goes through the copying pass (zk_project_dedupe)."""
+    if shift == 0 and ctx.first_descent(kmers) == kmers.n:
+        return kmers
+    return ctx.project_dedupe(kmers, shift)
+
