@@ -272,6 +272,9 @@ int zk_codec64_decode(const uint64_t* words, uint64_t nw, int delta, uint64_t* o
  * call with cap = 0 sizes the output). */
 int zk_codec64_encode_dev(zk_ctx* ctx, const uint64_t* d_vals, uint64_t n, int delta, uint64_t* d_words, uint64_t cap, uint64_t* n_words);
 int zk_codec64_decode_dev(zk_ctx* ctx, const uint64_t* d_words, uint64_t nw, int delta, uint64_t* d_out, uint64_t cap, uint64_t* n_out);
+/* zk_codec64_encode_dev (delta = 0) of 32-bit values: the counts of `zot kmerize` (array('I'), commands/kmerize.py:370-437) go into
+ * the 'counts' member (files.writeKmersAndCounts2, library/files.py:209-217) without being widened to 64 bits first; same words. */
+int zk_codec64_encode_u32_dev(zk_ctx* ctx, const uint32_t* d_vals, uint64_t n, uint64_t* d_words, uint64_t cap, uint64_t* n_words);
 
 /* files.undelta (library/files.py:100-110) of a PIECE of a delta stream: in-place inclusive prefix sum of the decoded
  * deltas, continued from `base` (the last k-mer before the piece; 0 for the first piece).  With zk_add_u64 (v[i] += x,

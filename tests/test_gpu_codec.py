@@ -76,3 +76,18 @@ def test_random_many_tiles_vs_oracle(ctx, n):
     big = np.cumsum(rng.integers(0, 1 << 44, size=min(n, 1 << 19), dtype=np.uint64), dtype=np.uint64)   # reaches beyond 2^57
     wb = ctx.codec_encode(ctx.upload(big), True)
     assert np.array_equal(ctx.codec_decode(wb, True, len(big)).to_host(), big)
+
+
+def test_encode_u32_counts_and_the_grown_word_buffer(ctx):
+    """32-bit counts are encoded without being widened (zk_codec64_encode_u32_dev): the same words as the 64-bit encoder gives
+    for the same values, and as the host codec (library/codec64.py:82-120).  Values of more than 30 bits take a word each: more
+    words than the half-a-word-per-value buffer the wrapper starts with, so the grown buffer is exercised too."""
+    rng = np.random.default_rng(17)
+    for n, hi in ((0, 4), (1, 4), (100003, 4), (300000, 12), (200000, 32), (70000, 31)):
+        v = (rng.integers(0, 1 << 62, size=n, dtype=np.uint64) >> rng.integers(64 - hi, 64, size=n, dtype=np.uint64).astype(np.uint64)).astype(np.uint32)
+        if n > 5000 and hi >= 31:
+            v[1000:60000] |= np.uint32(1 << 30)            # a long stretch of one-value words
+        want = zo.codec64_encode(v.astype(np.uint64))
+        got32 = ctx.codec_encode(ctx.upload(v), False).to_host() if n else np.empty(0, np.uint64)
+        got64 = ctx.codec_encode(ctx.upload(v.astype(np.uint64)), False).to_host() if n else np.empty(0, np.uint64)
+        assert np.array_equal(got32, want) and np.array_equal(got64, want), (n, hi)

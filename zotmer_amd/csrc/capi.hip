@@ -286,6 +286,12 @@ int zk_codec64_encode_dev(zk_ctx* c, const uint64_t* d_vals, uint64_t n, int del
     return codec_encode(c, (const u64*)d_vals, n, delta, (u64*)d_words, cap, n_words);
 }
 
+int zk_codec64_encode_u32_dev(zk_ctx* c, const uint32_t* d_vals, uint64_t n, uint64_t* d_words, uint64_t cap, uint64_t* n_words) {
+    ZK_ARGS(c, n_words);
+    arena_reset(c);
+    return codec_encode_u32(c, (const u32*)d_vals, n, (u64*)d_words, cap, n_words);
+}
+
 int zk_codec64_decode_dev(zk_ctx* c, const uint64_t* d_words, uint64_t nw, int delta, uint64_t* d_out, uint64_t cap, uint64_t* n_out) {
     ZK_ARGS(c, n_out);
     arena_reset(c);

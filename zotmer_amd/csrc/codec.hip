@@ -198,13 +198,15 @@ int codec_decode(zk_ctx* c, const u64* d_words, uint64_t nw, int delta, u64* d_o
 constexpr int ENC_CH = 32;                         // positions per thread (one chunk)
 constexpr int ENC_TILE = CD_BLOCK * ENC_CH;        // 8192 positions per tile
 
-__device__ __forceinline__ u64 enc_value(const u64* __restrict__ v, u64 i, int delta) {
-    return delta ? (i ? v[i] - v[i - 1] : v[i]) : v[i];
+template <class T>
+__device__ __forceinline__ u64 enc_value(const T* __restrict__ v, u64 i, int delta) {
+    return delta ? (i ? (u64)v[i] - (u64)v[i - 1] : (u64)v[i]) : (u64)v[i];
 }
 __device__ __forceinline__ int bit_length64(u64 x) { return x ? 64 - __builtin_clzll(x) : 0; }
 
 // greedy word length if a word started at position i: 0 marks a value with no code (>= 2^60)
-__global__ void enc_len_kernel(const u64* __restrict__ v, u64 n, int delta, u8* __restrict__ len, u32* err) {
+template <class T>
+__global__ void enc_len_kernel(const T* __restrict__ v, u64 n, int delta, u8* __restrict__ len, u32* err) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
         int cnt = 0, mw = 0;
 #pragma unroll
@@ -264,7 +266,8 @@ __device__ __forceinline__ u32 lookback_state(u64* status, u32 tile, u32 my_map,
     return entry;
 }
 
-__global__ __launch_bounds__(CD_BLOCK) void encode_kernel(const u64* __restrict__ v, u64 n, int delta, const u8* __restrict__ len,
+template <class T>
+__global__ __launch_bounds__(CD_BLOCK) void encode_kernel(const T* __restrict__ v, u64 n, int delta, const u8* __restrict__ len,
                                                           u64* __restrict__ words, u64 cap, u64* status_state, CdState st) {
     __shared__ EncSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -319,7 +322,9 @@ __global__ __launch_bounds__(CD_BLOCK) void encode_kernel(const u64* __restrict_
     if (tid == 0 && tile == st.tiles - 1 && sm.cd.tile_excl + tile_total > cap) atomicOr(st.err, ZK_DERR_CAPACITY);
 }
 
-int codec_encode(zk_ctx* c, const u64* d_vals, uint64_t n, int delta, u64* d_words, uint64_t cap, uint64_t* n_words) {
+// T: the values' type -- u64, or u32 (the counts of zot kmerize, encoded without being widened first)
+template <class T>
+static int codec_encode_t(zk_ctx* c, const T* d_vals, uint64_t n, int delta, u64* d_words, uint64_t cap, uint64_t* n_words) {
     *n_words = 0;
     if (n == 0) return ZK_OK;
     u8* len;
@@ -327,19 +332,25 @@ int codec_encode(zk_ctx* c, const u64* d_vals, uint64_t n, int delta, u64* d_wor
     ZK_TRY(arena_alloc(c, n + 64, (void**)&len));
     u64 g = div_up(n, 256 * 8);
     if (g > (u64)c->num_cus * 16) g = (u64)c->num_cus * 16;
-    hipLaunchKernelGGL(enc_len_kernel, dim3((u32)g), dim3(256), 0, c->stream, d_vals, (u64)n, delta, len, c->d_err);
+    hipLaunchKernelGGL((enc_len_kernel<T>), dim3((u32)g), dim3(256), 0, c->stream, d_vals, (u64)n, delta, len, c->d_err);
     ZK_HIP(c, hipGetLastError());
     CdState st;
     st.tiles = (u32)div_up(n, ENC_TILE);
     ZK_TRY(lookback_begin(c, 2ull * st.tiles, st.tiles, &st.epoch, &st.ticket_base));
     st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9;
-    hipLaunchKernelGGL(encode_kernel, dim3(st.tiles), dim3(CD_BLOCK), 0, c->stream, d_vals, (u64)n, delta, len, d_words, (u64)cap,
+    hipLaunchKernelGGL((encode_kernel<T>), dim3(st.tiles), dim3(CD_BLOCK), 0, c->stream, d_vals, (u64)n, delta, len, d_words, (u64)cap,
                        c->status + st.tiles, st);
     ZK_HIP(c, hipGetLastError());
     ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, c->d_scalars + 9, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     *n_words = c->h_scalars[9];
     return check_device_error(c);
+}
+int codec_encode(zk_ctx* c, const u64* d_vals, uint64_t n, int delta, u64* d_words, uint64_t cap, uint64_t* n_words) {
+    return codec_encode_t<u64>(c, d_vals, n, delta, d_words, cap, n_words);
+}
+int codec_encode_u32(zk_ctx* c, const u32* d_vals, uint64_t n, u64* d_words, uint64_t cap, uint64_t* n_words) {
+    return codec_encode_t<u32>(c, d_vals, n, 0, d_words, cap, n_words);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -184,6 +184,7 @@ int count_hist(zk_ctx* c, const void* counts, int count_bits, uint64_t n, uint64
 int codec_decode(zk_ctx* c, const u64* d_words, uint64_t nw, int delta, u64* d_out, uint64_t cap, uint64_t* n_out);
 int fastq_mask(zk_ctx* c, const u8* d_text, uint64_t n, uint32_t line_phase, u8* d_out, uint64_t* n_newlines);
 int codec_encode(zk_ctx* c, const u64* d_vals, uint64_t n, int delta, u64* d_words, uint64_t cap, uint64_t* n_words);
+int codec_encode_u32(zk_ctx* c, const u32* d_vals, uint64_t n, u64* d_words, uint64_t cap, uint64_t* n_words);
 int scan64_inclusive(zk_ctx* c, u64* d_v, uint64_t n);   // in place, asynchronous
 int add_u64(zk_ctx* c, u64* d_v, uint64_t n, u64 x);     // v[i] += x, asynchronous
 // ingest.hip

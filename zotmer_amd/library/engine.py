@@ -78,24 +78,7 @@ def batch_bytes_for(ctx, requested=None, input_bytes=None):
     return min(b, 6 << 30)
 
 
-_TIMING = os.environ.get("ZOT_TIMING") == "2"
-
-
-class _Phase:
-    """ZOT_TIMING=2: wall time of the phases of a batch on stderr (development aid)"""
-
-    def __init__(self, ctx, what):
-        self.ctx, self.what = ctx, what
-
-    def __enter__(self):
-        if _TIMING:
-            self.ctx.sync()
-            self.t = time.perf_counter()
-
-    def __exit__(self, *a):
-        if _TIMING:
-            self.ctx.sync()
-            sys.stderr.write("  [engine] %-28s %8.1f ms\n" % (self.what, (time.perf_counter() - self.t) * 1e3))
+from zotmer_amd.library.timing import Phase as _Phase
 
 
 class Slab:
@@ -348,7 +331,8 @@ def count_fastq_file(ctx, table, path, batch_bytes, take=None):
                 ctx._check(ctx.lib.zk_upload(ctx.h, buf.ptr + cut, b"\n", 1))      # the last line counts without a terminator
                 cut += 1
             if cut:
-                stream, nl = ctx.fastq_mask(buf.view(cut), lines % 4, out=masked.view(cut))
+                with _Phase(ctx, "fastq_mask", cut):
+                    stream, nl = ctx.fastq_mask(buf.view(cut), lines % 4, out=masked.view(cut))
                 if eof and (lines + nl) % 4:
                     # an incomplete final record: file.readFastq drops it (file.py:51-52) -- find where its lines start and
                     # mask again without them (malformed input only; the tail is scanned on the host)

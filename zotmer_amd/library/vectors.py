@@ -8,6 +8,8 @@ import ctypes as C
 
 import numpy as np
 
+from zotmer_amd.library.timing import Phase
+
 from zotmer_amd import native
 
 
@@ -113,8 +115,7 @@ def device_encode_counts(ctx, counts_dev):
     """uint32 / uint64 counts on the device -> bytes of the 'counts' member"""
     if counts_dev.n == 0:
         return b""
-    c64 = ctx.widen(counts_dev) if counts_dev.dtype.itemsize == 4 else counts_dev
-    return _check_codec(ctx.codec_encode, c64, False).to_host().astype("<u8", copy=False).tobytes()
+    return _check_codec(ctx.codec_encode, counts_dev, False).to_host().astype("<u8", copy=False).tobytes()
 
 
 def device_write_kmers_and_counts(ctx, z, kmers_dev, counts_dev):
@@ -124,19 +125,25 @@ def device_write_kmers_and_counts(ctx, z, kmers_dev, counts_dev):
         z.add("kmers", b"")
         z.add("counts", b"")
         return
-    words = _check_codec(ctx.codec_encode, kmers_dev, True)
-    z.add_device("kmers", ctx, words)
+    with Phase(ctx, "codec64 encode k-mers", kmers_dev.nbytes):
+        words = _check_codec(ctx.codec_encode, kmers_dev, True)
+    with Phase(ctx, "write k-mers", words.nbytes):
+        z.add_device("kmers", ctx, words)
     del words
-    c64 = ctx.widen(counts_dev) if counts_dev.dtype.itemsize == 4 else counts_dev
-    words = _check_codec(ctx.codec_encode, c64, False)
-    z.add_device("counts", ctx, words)
+    with Phase(ctx, "codec64 encode counts", counts_dev.nbytes):
+        words = _check_codec(ctx.codec_encode, counts_dev, False)          # 32-bit counts are encoded as they are
+    with Phase(ctx, "write counts", words.nbytes):
+        z.add_device("counts", ctx, words)
 
 
 def device_read_kmers(ctx, z):
     """'kmers' member -> uint64 k-mers on the device"""
     if z.member_size("kmers") == 0:
         return ctx.empty(0, np.uint64)
-    return _check_codec(ctx.codec_decode, z.read_device("kmers", ctx, "<u8"), True)
+    with Phase(ctx, "read k-mers", z.member_size("kmers")):
+        w = z.read_device("kmers", ctx, "<u8")
+    with Phase(ctx, "codec64 decode k-mers", w.nbytes):
+        return _check_codec(ctx.codec_decode, w, True)
 
 
 def device_read_kmers_and_counts(ctx, z):

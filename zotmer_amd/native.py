@@ -87,6 +87,7 @@ SIGNATURES = {
     "zk_codec64_count": (_i, [_vp, _u64, _pu64]),
     "zk_codec64_decode": (_i, [_vp, _u64, _i, _vp, _u64, _pu64]),
     "zk_codec64_encode_dev": (_i, [_vp, _vp, _u64, _i, _vp, _u64, _pu64]),
+    "zk_codec64_encode_u32_dev": (_i, [_vp, _vp, _u64, _vp, _u64, _pu64]),
     "zk_codec64_decode_dev": (_i, [_vp, _vp, _u64, _i, _vp, _u64, _pu64]),
     "zk_fastq_mask": (_i, [_vp, _vp, _u64, _u32, _vp, _pu64]),
     "zk_source_open": (_vp, [_vp, C.c_char_p, _i]),
@@ -495,11 +496,24 @@ class Context:
         return tuple(int(v) for v in abc)
 
     def codec_encode(self, values, delta):
-        """uint64 device values -> device codec64 words (delta=True: ascending k-mers, stored as differences)."""
-        words = self.empty(values.n, np.uint64)
+        """uint64 (or, delta=False, uint32) device values -> device codec64 words (delta=True: ascending k-mers, stored as
+        differences).  The word buffer starts at half a word per value (device memory costs ~25 ms per GB to allocate: sorted
+        k-mers pack three to a word, counts six) and is grown to the worst case, one word per value, only if that is too small."""
         n = C.c_uint64(0)
-        self._check(self.lib.zk_codec64_encode_dev(self.h, values.ptr, values.n, int(delta), words.ptr, words.n, C.byref(n)))
-        return words.view(n.value)
+        for cap in ((values.n + 1) // 2 + 1024, values.n):
+            cap = min(cap, values.n)
+            words = self.empty(cap, np.uint64)
+            if values.dtype.itemsize == 4:
+                if delta:
+                    raise ValueError("delta coding is for 64-bit k-mers")
+                rc = self.lib.zk_codec64_encode_u32_dev(self.h, values.ptr, values.n, words.ptr, words.n, C.byref(n))
+            else:
+                rc = self.lib.zk_codec64_encode_dev(self.h, values.ptr, values.n, int(delta), words.ptr, words.n, C.byref(n))
+            if rc == ZK_ENOSPC and cap < values.n:
+                del words
+                continue
+            self._check(rc)
+            return words.view(n.value)
 
     def codec_decode(self, words, delta, n_values=None):
         """device codec64 words -> uint64 device values (delta=True also undoes the k-mer differences)."""
