@@ -239,7 +239,8 @@ class KmerTable:
             self._merge_top()
 
     def _merge_top(self):
-        """union-sum the two tables on top of the stack into one: into the scratch slab, then back over the inputs"""
+        """union-sum the two tables on top of the stack into one: into the scratch slab, then back over the inputs (or, at the
+        bottom of the stack, the slabs swap)"""
         ctx, slab, scratch = self.ctx, self.slab, self.scratch
         ob, nb, lb = self.stack.pop()
         oa, na, la = self.stack.pop()
@@ -250,13 +251,31 @@ class KmerTable:
         if n_out >= self.EXACT_FROM:
             with _Phase(ctx, "intersect (size the union)"):
                 n_out -= ctx.split(ak, bk)[0]
+        # The two tables at the bottom of the stack (the big merges): the union is not copied back -- the two slabs change
+        # roles, the scratch slab with the union in it becomes the table slab.  For that it must be as large as the table
+        # slab is (or the next batch would have to grow it, with a copy); if memory does not allow that, copy back as above
+        # the bottom.
+        swap = oa == 0
+        if swap and scratch.E < slab.E:
+            free, _ = ctx.mem_info()
+            if 12 * slab.E + (2 << 30) < free + 12 * scratch.E:          # (growing frees the old scratch first: nothing in it is live)
+                scratch.ensure(slab.E)
+            else:
+                swap = False
         scratch.ensure(n_out)
         with _Phase(ctx, "union_sum %d + %d" % (na, nb)):
             mk, mc = ctx.union_sum(ak, ac, bk, bc, out=(scratch.k.view(n_out), scratch.c.view(n_out)))
             n = mk.n
-            ctx._check(ctx.lib.zk_copy(ctx.h, slab.k.ptr + 8 * oa, mk.ptr, 8 * n))
-            ctx._check(ctx.lib.zk_copy(ctx.h, slab.c.ptr + 4 * oa, mc.ptr, 4 * n))
-            ctx.sync()
+            if swap:
+                ctx.sync()
+                del ak, ac, bk, bc, mk, mc
+                slab.k, scratch.k = scratch.k, slab.k
+                slab.c, scratch.c = scratch.c, slab.c
+                slab.E, scratch.E = scratch.E, slab.E
+            else:
+                ctx._check(ctx.lib.zk_copy(ctx.h, slab.k.ptr + 8 * oa, mk.ptr, 8 * n))
+                ctx._check(ctx.lib.zk_copy(ctx.h, slab.c.ptr + 4 * oa, mc.ptr, 4 * n))
+                ctx.sync()
         self.stack.append((oa, n, max(la, lb) + 1))
         self.top = oa + n
 
