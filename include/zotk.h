@@ -79,6 +79,8 @@ int zk_upload_async(zk_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 #define ZK_TUNE_STREAM_PASS 10   /* the first sort pass of zk_kmerize / zk_sort_stream: 1 (default) = static stream ranges, whole 64-byte units written
                                   * out of LDS (stream_pass.hip); 2 = the same with 32-byte units (measurements); 0 = the look-back pipeline */
 #define ZK_TUNE_STREAM_RANGES 11 /* ... the number of ranges the stream is cut into, one workgroup each (0 = one per CU, the default; <= 4096) */
+#define ZK_TUNE_TAG_WORDS 12     /* zk_kmerize: 1 (default) = the pass before the block dedupe writes 32-bit tags instead of whole keys when the key bits
+                                  * below the blocks fit (K <= 25 after two passes); 0 = whole keys */
 #define ZK_TUNE_COMM_CHUNK 6     /* zk_all_to_all_v: bytes per message and round (0 = 256 MiB, the default) */
 int zk_tune(zk_ctx* ctx, int what, int value);
 

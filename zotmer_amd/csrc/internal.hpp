@@ -28,6 +28,8 @@ struct zk_ctx {
     int pairs_variant = 2;     // ... for (key, u32) pairs
     int stream_pass = 1;       // the first sort pass (from the base stream): 1 = static ranges, whole 64-byte units written from LDS
                                // (stream_pass.hip; 2 = 32-byte units, for measurements), 0 = the look-back pipeline
+    int tag_words = 1;         // zk_kmerize, block dedupe after two passes with at most 32 key bits below the blocks: the second pass writes
+                               // only those bits, as 32-bit tags (radix_sort.hip); 0 = whole keys
     int stream_ranges = 0;     // ... ranges the stream is cut into (0 = one per CU; tests use a few so that a range has many tiles)
 
     // workspace arena: a bump allocator reset at the start of every API call
@@ -131,7 +133,11 @@ int sort_pairs_mirrored(zk_ctx* c, const u64* src_k, const u32* src_v, u64* keys
 // few whole blocks of the block dedupe: every copy of their k-mers), and if more than max_ratio of them are distinct the sort is
 // declined (return 1, nothing sorted) -- the caller then plans for an input that does not repeat its k-mers.
 struct StreamSample { int shift; uint64_t value; double max_ratio; uint64_t seen = 0, distinct = 0; };
-struct StreamSrc { const u8* stream; uint64_t n_bytes; int K; int mode; int lo_bit; int hi_bit = 0; StreamSample* sample = nullptr; };   // mode: ZK_KEYS_*; sort bits [lo_bit, hi_bit) (hi_bit 0 = 2K)
+// Ask sort_stream to let the last of its two passes write the keys' low 32 bits only (the bits [32, 2K) are the ones sorted:
+// lo_bit == 32): *result is then a u32 array, and `cuts` says where each block of equal sorted bits starts (see tag_cuts_kernel).
+struct StreamTags { bool written = false; u64* cuts = nullptr; uint32_t blocks = 0; };
+struct StreamSrc { const u8* stream; uint64_t n_bytes; int K; int mode; int lo_bit; int hi_bit = 0; StreamSample* sample = nullptr;
+                   StreamTags* tags = nullptr; };   // mode: ZK_KEYS_*; sort bits [lo_bit, hi_bit) (hi_bit 0 = 2K)
 int sort_rbits(zk_ctx* c);
 int sort_first_bits(zk_ctx* c, int key_bits, int lo_bit);
 struct DedupeResult {
@@ -144,7 +150,9 @@ struct DedupeResult {
     int pack = 0;
 };
 int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int pack, u64* work, uint64_t cap, DedupeResult* r,
-                uint64_t* n_in = nullptr, uint64_t max_chunks = 0);
+                uint64_t* n_in = nullptr, uint64_t max_chunks = 0, const u32* tags = nullptr, const u64* tag_cuts = nullptr);
+// the keys back from their tags: key = (block number << tag_bits) | tag
+int expand_tags(zk_ctx* c, const u32* tags, const u64* cuts, uint32_t blocks, int tag_bits, u64* keys_out, uint64_t first_block = 0, uint64_t n_blocks = 0);
 int dedupe_finish(zk_ctx* c, const DedupeResult& r, u64* out_k, u32* out_c, u64* out_m = nullptr, int K = 0, int gbases = 0,
                   u64** mirror_hist = nullptr, int* mirror_group_bits = nullptr);
 int sort_keys_upper_counted(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, int lo_bit, u64* counted, u64** result);

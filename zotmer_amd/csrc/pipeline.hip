@@ -268,15 +268,19 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     uint64_t n = 0;
     u64* sorted = nullptr;
     bool presampled = false;
+    StreamTags stags;          // set when the last pass wrote 32-bit tags instead of keys (`sorted` is then a u32 array)
     if (dedupe_bit) {
         // Sorting the top bits first only pays if the blocks can then be counted; an input that does not repeat its k-mers would
         // have to start over.  So the histogram kernel sets aside four whole blocks (prefixes AAATCCTA.: every copy of their
         // k-mers) and the sort is declined when they show little duplication -- at the price of one more histogram run.
         StreamSample smp{2 * K - dedupe_bit + 2, (uint64_t)(0x0D71C8E5u >> (32 - (dedupe_bit - 2))), 0.6};
         src.lo_bit = 2 * K - dedupe_bit; src.hi_bit = 0; src.sample = &smp;
+        // at most 32 key bits below the blocks: the last pass may write just those (sort_stream decides; K = 25 after two passes)
+        if (c->tag_words && src.lo_bit <= 32) src.tags = &stags;
         const int rc = sort_stream(c, src, buf_a, buf_b, cap_keys, &n, st->acgt, &sorted);
         if (rc < 0) return rc;
         src.sample = nullptr;
+        src.tags = nullptr;
         if (rc == 1) { dedupe_bit = 0; src.lo_bit = 0; }
         presampled = smp.seen >= 4096;          // the look was conclusive: no second one after the passes
     }
@@ -307,9 +311,10 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
         bool done = false;
         // the sample: the leading blocks, about a million keys
         const uint64_t nblocks = 1ull << dedupe_bit, per = n / nblocks + 1;
-        if (!presampled) ZK_TRY(dedupe_pass(c, sorted, n, 2 * K, dedupe_bit, pk, other, cap_keys, &r, &n_in, (1u << 20) / per + 4));
+        const u32* tg = stags.written ? (const u32*)sorted : nullptr;
+        if (!presampled) ZK_TRY(dedupe_pass(c, sorted, n, 2 * K, dedupe_bit, pk, other, cap_keys, &r, &n_in, (1u << 20) / per + 4, tg, stags.cuts));
         if (presampled || (!(r.flags & 1) && (double)r.n_out <= 0.6 * (double)n_in)) {
-            ZK_TRY(dedupe_pass(c, sorted, n, 2 * K, dedupe_bit, pk, other, cap_keys, &r));
+            ZK_TRY(dedupe_pass(c, sorted, n, 2 * K, dedupe_bit, pk, other, cap_keys, &r, nullptr, 0, tg, stags.cuts));
             if (!(r.flags & 1)) {
                 uc = r.n_out;
                 const uint64_t a8 = (8 * uc + 255) & ~255ull, a4 = (4 * uc + 255) & ~255ull;
@@ -332,6 +337,11 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
             // little duplication, or a table filled up: the keys (untouched: the words went to the other buffer) are sorted the
             // long way, all their bits -- the two passes over the top bits were for nothing
             u64* res = nullptr;
+            if (tg) {
+                // ... made again from their tags first (into the buffer the discarded words are in)
+                ZK_TRY(expand_tags(c, tg, stags.cuts, stags.blocks, 2 * K - dedupe_bit, other));
+                u64* t = sorted; sorted = other; other = t;
+            }
             ZK_TRY(sort_keys(c, sorted, other, n, 2 * K, &res));
             sorted = res;
             other = (sorted == buf_a) ? buf_b : buf_a;
@@ -530,7 +540,7 @@ int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, dou
     arena_reset(c);
     // histograms, merge-path partitions, the mirror group tables (4 MB); from 2^29 stream bytes on (block dedupe with 2^18 blocks) the
     // blocks' tables as well: bounds, sizes, and the 2^24 run places of the mirror grouping (336 MB)
-    const uint64_t slack = (9 << 20) + cap_keys / 16 + (n_bytes >= (1ull << 29) ? (384ull << 20) : 0);
+    const uint64_t slack = (16 << 20) + cap_keys / 16 + (n_bytes >= (1ull << 29) ? (384ull << 20) : 0);          // (+ the block starts of the tag path: 2 MB)
     ZK_TRY(arena_require(c, 16 * cap_keys + slack, 16 * cap_keys + slack));
     u64 *buf_a, *buf_b;
     ZK_TRY(arena_alloc(c, 8 * cap_keys, (void**)&buf_a));

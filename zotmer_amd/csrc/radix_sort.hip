@@ -83,6 +83,8 @@ struct SortArgs {
     // outputs
     u64* kout;
     u32* vout;
+    int tags_out;       // pipeline, array source: the pass writes only the low 32 bits of a key, as a u32 array at kout (the last pass
+                        // before the block dedupe: the bits above are the block's number, which the key's place says)
     // digit of this pass
     int shift;
     int bits;
@@ -960,6 +962,7 @@ struct DedupeSmem {
 
 struct DedupeArgs {
     const u64* kin;
+    const u32* tin;     // or: the keys' low 32 bits only (TAGIN; the bits above are the block's number)
     u64 n;
     const u64* cuts;    // [chunks + 1]: chunk v = the block of keys whose top bits are v
     u64* out;           // block v writes its words from out + cuts[v] on; dedupe_unpack_kernel closes the gaps
@@ -999,7 +1002,7 @@ struct DedupeNext {
     u64 key[ITEMS];
 };
 
-template <bool TAG32>
+template <bool TAG32, bool TAGIN>
 __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG32>& sm, DedupeNext<DedupeSmem<TAG32>::ITEMS>& st) {
     using S = DedupeSmem<TAG32>;
     using E = typename S::E;
@@ -1012,7 +1015,26 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
     const u32 maxc = (1u << a.pack) - 1u;
     // whole tiles: one address, constant offsets; the cut last tile: per-key bounds
     auto load = [&](u64 base, u64 end, u64 (&k)[ITEMS]) {
-        if (base + TILE <= end) {
+        if constexpr (TAGIN) {
+            // (a tag is a whole key as far as the table goes: the block's bits are added when the words are written)
+            if (base + TILE <= end) {
+                // four tags per load (16 bytes a lane, a kilobyte a wave instruction; which thread takes which key is the table's
+                // business alone); a block starts wherever it starts: the loads are 4-byte aligned, no more
+                struct __attribute__((packed, aligned(4))) Tag4 { u32 a, b, c, d; };
+                static_assert(ITEMS % 4 == 0, "whole quads");
+#pragma unroll
+                for (int i = 0; i < ITEMS / 4; i++) {
+                    const Tag4 q = *reinterpret_cast<const Tag4*>(a.tin + base + (u64)i * (4 * BLOCK) + 4 * tid);
+                    k[4 * i] = q.a; k[4 * i + 1] = q.b; k[4 * i + 2] = q.c; k[4 * i + 3] = q.d;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < ITEMS; i++) {
+                    const u64 g = base + (u64)i * BLOCK + tid;
+                    k[i] = g < end ? (u64)a.tin[g] : ~0ull;
+                }
+            }
+        } else if (base + TILE <= end) {
             const u64* p = a.kin + base + tid;
 #pragma unroll
             for (int i = 0; i < ITEMS; i++) k[i] = p[i * BLOCK];
@@ -1176,9 +1198,10 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
 
 // Persistent: one workgroup per CU (the table takes most of its LDS) draws the blocks from a counter -- in order, not strided:
 // the sizes go with the first bases, a stride of the grid would give one workgroup all the big ones.
-template <bool TAG32>
+template <bool TAG32, bool TAGIN = false>
 __global__ __launch_bounds__(1024, 4) void dedupe_kernel(DedupeArgs a) {
     using S = DedupeSmem<TAG32>;
+    static_assert(TAG32 || !TAGIN, "32-bit tags in, 32-bit tags in the table");
     __shared__ S sm;
     DedupeNext<S::ITEMS> st;
     if (threadIdx.x == 0) sm.ticket = atomicAdd(a.counter, 1u);
@@ -1189,11 +1212,12 @@ __global__ __launch_bounds__(1024, 4) void dedupe_kernel(DedupeArgs a) {
 #pragma unroll
     for (int i = 0; i < S::ITEMS; i++) {
         const u64 g = st.lo + (u64)i * S::BLOCK + threadIdx.x;
-        st.key[i] = g < st.hi ? a.kin[g] : ~0ull;
+        if constexpr (TAGIN) st.key[i] = g < st.hi ? (u64)a.tin[g] : ~0ull;
+        else st.key[i] = g < st.hi ? a.kin[g] : ~0ull;
     }
     __syncthreads();          // the ticket word is free again
     while (st.chunk < a.chunks) {
-        dedupe_block<TAG32>(a, sm, st);          // leaves the next block in st
+        dedupe_block<TAG32, TAGIN>(a, sm, st);          // leaves the next block in st
         __syncthreads();          // the table and the ticket word are free again
     }
 }
@@ -1351,8 +1375,8 @@ struct PipeSmem {
     u32 total_live;
 };
 
-// VAR only names the instantiation: 1 = the upper-bit passes over collapsed lists of packed words, so that a profiler lists them
-// apart from the dominant full-size passes (same code).
+// VAR: 1 only names the instantiation = the upper-bit passes over collapsed lists of packed words, so that a profiler lists them
+// apart from the dominant full-size passes (same code); 2 = the pass stores the keys' low 32 bits only (SortArgs::tags_out).
 template <class C, int SRC, int VAR = 0>
 __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a, u32 tiles) {
     constexpr int BLOCK = C::BLOCK, ITEMS = C::ITEMS, RADIX = C::RADIX, NW = C::NW, DPT = C::DPT, TILE = C::TILE;
@@ -1666,7 +1690,10 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                 for (int g = 0; g < G; g++) pos[g] = sm.gbase[(u32)(kk[g] >> a.shift) & dmask] + (slot0 + (i0 + g) * BLOCK);
 #pragma unroll
                 for (int g = 0; g < G; g++)
-                    if (slot0 + (i0 + g) * BLOCK < totalA) a.kout[pos[g]] = kk[g];
+                    if (slot0 + (i0 + g) * BLOCK < totalA) {
+                        if constexpr (VAR == 2) reinterpret_cast<u32*>(a.kout)[pos[g]] = (u32)kk[g];
+                        else a.kout[pos[g]] = kk[g];
+                    }
             }
         }
 #ifdef ZK_STAMPS
@@ -1710,6 +1737,32 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
             }
         }
     }
+}
+
+// Where do the blocks of the block dedupe start when the last pass has written tags (no key to search for)?  Block (dh, v) --
+// dh the last pass's digit, v the digit of the pass before it -- starts at
+//     (keys with a smaller dh) + (keys with this dh in the tiles before the one where bucket v of the pass's input begins)
+//                              + (keys with this dh in that tile before bucket v)
+// the first from the pass's histogram, the second from the offsets its scanners published per tile (still in the status words),
+// the third counted here from the pass's input, a tile's worth per v.  One workgroup per v.
+__global__ __launch_bounds__(512) void tag_cuts_kernel(const u64* __restrict__ kin, u64 n, const u64* __restrict__ ghist_in, const u64* __restrict__ ghist_d,
+                                                       const u64* __restrict__ status, u32 stride, u32 tile, u32 tiles, int shift, int bits_d, int bits_in,
+                                                       u64* __restrict__ cuts) {
+    __shared__ u32 corr[1024];
+    const u32 v = blockIdx.x, Rd = 1u << bits_d, Rin = 1u << bits_in;
+    for (u32 d = threadIdx.x; d < Rd; d += blockDim.x) corr[d] = 0;
+    __syncthreads();
+    const u64 boundary = ghist_in[v];
+    const u64 tv = boundary / tile;
+    for (u64 i = tv * tile + threadIdx.x; i < boundary; i += blockDim.x) atomicAdd(&corr[(u32)(kin[i] >> shift) & (Rd - 1u)], 1u);
+    __syncthreads();
+    for (u32 d = threadIdx.x; d < Rd; d += blockDim.x) {
+        u64 before;
+        if (tv < tiles) before = status[tv * stride + d] & ZK_ST_VALUE_MASK;
+        else before = (d + 1 < Rd ? ghist_d[d + 1] : n) - ghist_d[d];          // the bucket begins at the very end: every key of dh lies before it
+        cuts[(u64)d * Rin + v] = ghist_d[d] + before + corr[d];
+    }
+    if (v == 0 && threadIdx.x == 0) cuts[(u64)Rd * Rin] = n;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1772,8 +1825,10 @@ struct Sorter {
         a.dbg = c->dbg;
         a.dbg2 = c->dbg ? c->dbg + 8ull * tiles : nullptr;
         prof_begin(c, SRC == SRC_STREAM ? ZK_PROF_PASS_STREAM : (a.prof_tag ? a.prof_tag : ZK_PROF_PASS_KEYS),
-                   SRC == SRC_STREAM ? a.n_bytes + 8 * a.n : 16 * a.n);
-        if (SRC == SRC_ARRAY && a.prof_tag == ZK_PROF_PASS_PACKED)
+                   SRC == SRC_STREAM ? a.n_bytes + 8 * a.n : (a.tags_out ? 12 : 16) * a.n);
+        if (SRC == SRC_ARRAY && a.tags_out)
+            hipLaunchKernelGGL((pass_pipe_kernel<C, SRC_ARRAY, 2>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
+        else if (SRC == SRC_ARRAY && a.prof_tag == ZK_PROF_PASS_PACKED)
             hipLaunchKernelGGL((pass_pipe_kernel<C, SRC, 1>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
         else
             hipLaunchKernelGGL((pass_pipe_kernel<C, SRC, 0>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
@@ -1781,6 +1836,11 @@ struct Sorter {
         ZK_HIP(c, hipGetLastError());
       }
       return ZK_OK;
+    }
+    // keys per tile of the geometry launch_keys_pass uses for this many keys
+    static u32 keys_pass_tile(zk_ctx* c, uint64_t n) {
+        if constexpr (C::PIPE && C::RBITS == 9 && C::BLOCK == 512) { if (c->wide_tiles && n <= WIDE_TILES_MAX_KEYS) return 16384u; }
+        return (u32)C::TILE;
     }
     static int launch_keys_pass(zk_ctx* c, const SortArgs& a) {
         // the default geometry hands its array passes to the 16 K-key tiles (same digits, same histograms) while the array is
@@ -1967,10 +2027,24 @@ struct Sorter {
         }
         u64* in = buf_a; u64* out = buf_b;
         a.rec = 0;
+        // the block dedupe comes next and a key's low 32 bits are all it needs: the last of two passes writes those only
+        const bool tags = src.tags && C::PIPE && plan.passes == 2 && plan.shift[0] <= 32 && src.mode == ZK_KEYS_CANONICAL;
         for (int p = 1; p < plan.passes; p++) {
             a.kin = in; a.kout = out; a.shift = plan.shift[p]; a.bits = plan.bits[p];
             a.ghist = ghist + p * C::RADIX;
+            a.tags_out = (tags && p == plan.passes - 1) ? 1 : 0;
             ZK_TRY(launch_keys_pass(c, a));
+            if (a.tags_out) {
+                const u32 tile = keys_pass_tile(c, n), tiles = (u32)div_up(n, tile);
+                const uint64_t blocks = 1ull << (plan.bits[0] + plan.bits[1]);
+                u64* cuts;
+                ZK_TRY(arena_alloc(c, sizeof(u64) * (blocks + 1), (void**)&cuts));
+                hipLaunchKernelGGL(tag_cuts_kernel, dim3(1u << plan.bits[0]), dim3(512), 0, c->stream, (const u64*)in, (u64)n, (const u64*)ghist,
+                                   (const u64*)(ghist + C::RADIX), (const u64*)c->status, (u32)C::RADIX, tile, tiles, plan.shift[1], plan.bits[1],
+                                   plan.bits[0], cuts);
+                ZK_HIP(c, hipGetLastError());
+                src.tags->cuts = cuts; src.tags->blocks = (uint32_t)blocks; src.tags->written = true;
+            }
             u64* t = in; in = out; out = t;
         }
         *result = in;
@@ -2068,8 +2142,24 @@ int sort_first_bits(zk_ctx* c, int key_bits, int lo_bit) {
 //                 *flags: bit 0 = some table filled up (the words are not to be used), bit 1 = some counts went to the side list.
 //                 max_chunks > 0: only the leading blocks (the sample; *n_in = the keys they cover).
 //   dedupe_finish moves the words together and apart into out_k / out_c (r.n_out entries each).
+__global__ void expand_tags_kernel(const u32* __restrict__ tags, const u64* __restrict__ cuts, u64 first_block, u64 n_blocks, int tag_bits, u64* __restrict__ out) {
+    for (u64 v = first_block + blockIdx.x; v < first_block + n_blocks; v += gridDim.x) {
+        const u64 lo = cuts[v], hi = cuts[v + 1], top = v << tag_bits;
+        for (u64 i = lo + threadIdx.x; i < hi; i += blockDim.x) out[i] = top | (u64)tags[i];
+    }
+}
+
+int expand_tags(zk_ctx* c, const u32* tags, const u64* cuts, uint32_t blocks, int tag_bits, u64* keys_out, uint64_t first_block, uint64_t n_blocks) {
+    if (n_blocks == 0) { first_block = 0; n_blocks = blocks; }
+    const uint64_t mx = (uint64_t)c->num_cus * 16;
+    hipLaunchKernelGGL(expand_tags_kernel, dim3((u32)(n_blocks < mx ? n_blocks : mx)), dim3(256), 0, c->stream, tags, cuts, (u64)first_block, (u64)n_blocks,
+                       tag_bits, keys_out);
+    ZK_HIP(c, hipGetLastError());
+    return ZK_OK;
+}
+
 int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int pack, u64* work, uint64_t cap, DedupeResult* r,
-                uint64_t* n_in, uint64_t max_chunks) {
+                uint64_t* n_in, uint64_t max_chunks, const u32* tags, const u64* tag_cuts) {
     *r = DedupeResult();
     if (n_in) *n_in = n;
     if (n == 0) return ZK_OK;
@@ -2080,13 +2170,16 @@ int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int
     if (max_chunks && chunks > max_chunks) chunks = max_chunks;
     u64 *cuts, *nwords, *incl, *big;
     const u32 big_cap = 1u << 16;
-    ZK_TRY(arena_alloc(c, sizeof(u64) * (chunks + 1), (void**)&cuts));
+    if (tags) {
+        if (!tag_cuts || key_bits - b > 32) return fail(c, ZK_EINTERNAL, "dedupe_pass: tags of %d bits", key_bits - b);
+        cuts = const_cast<u64*>(tag_cuts);
+    } else ZK_TRY(arena_alloc(c, sizeof(u64) * (chunks + 1), (void**)&cuts));
     ZK_TRY(arena_alloc(c, sizeof(u64) * chunks, (void**)&nwords));
     ZK_TRY(arena_alloc(c, sizeof(u64) * chunks, (void**)&incl));
     ZK_TRY(arena_alloc(c, sizeof(u64) * 2 * big_cap, (void**)&big));
     a.tag_bits = key_bits - b;
-    hipLaunchKernelGGL(dedupe_cuts_kernel, dim3((u32)div_up(chunks + 1, 256)), dim3(256), 0, c->stream, keys, (u64)n, a.tag_bits, (u32)chunks, cuts);
-    a.kin = keys; a.n = n; a.cuts = cuts; a.out = work; a.nwords = nwords; a.pack = pack;
+    if (!tags) hipLaunchKernelGGL(dedupe_cuts_kernel, dim3((u32)div_up(chunks + 1, 256)), dim3(256), 0, c->stream, keys, (u64)n, a.tag_bits, (u32)chunks, cuts);
+    a.kin = keys; a.tin = tags; a.n = n; a.cuts = cuts; a.out = work; a.nwords = nwords; a.pack = pack;
     a.chunks = (u32)chunks;
     a.flags = (u32*)(c->d_scalars + 27);
     a.counter = (u32*)(c->d_scalars + 29);
@@ -2104,8 +2197,9 @@ int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int
     ZK_HIP(c, hipMemsetAsync(c->d_scalars + 27, 0, 5 * sizeof(u64), c->stream));
     prof_begin(c, ZK_PROF_RLE, 8 * n);
     const u32 grid = chunks < (uint64_t)c->num_cus ? (u32)chunks : (u32)c->num_cus;
-    if (a.tag_bits <= 32) hipLaunchKernelGGL(dedupe_kernel<true>, dim3(grid), dim3(1024), 0, c->stream, a);
-    else hipLaunchKernelGGL(dedupe_kernel<false>, dim3(grid), dim3(1024), 0, c->stream, a);
+    if (tags) hipLaunchKernelGGL((dedupe_kernel<true, true>), dim3(grid), dim3(1024), 0, c->stream, a);
+    else if (a.tag_bits <= 32) hipLaunchKernelGGL((dedupe_kernel<true, false>), dim3(grid), dim3(1024), 0, c->stream, a);
+    else hipLaunchKernelGGL((dedupe_kernel<false, false>), dim3(grid), dim3(1024), 0, c->stream, a);
     prof_end(c);
     ZK_HIP(c, hipGetLastError());
     ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 27, c->d_scalars + 27, 5 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
@@ -2126,11 +2220,17 @@ int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int
             ZK_HIP(c, hipMemcpy(lohi, cuts + list[i], 2 * sizeof(u64), hipMemcpyDeviceToHost));
             const uint64_t m = lohi[1] - lohi[0];
             u64* res = nullptr;
-            ZK_TRY(sort_keys(c, const_cast<u64*>(keys) + lohi[0], work + lohi[0], m, a.tag_bits, &res));
-            if (res != keys + lohi[0]) ZK_HIP(c, hipMemcpyAsync(const_cast<u64*>(keys) + lohi[0], res, 8 * m, hipMemcpyDeviceToDevice, c->stream));
+            u64* bk = const_cast<u64*>(keys) + lohi[0];          // the block's keys, sorted in place
+            if (tags) {
+                // only tags were written: the block's keys are made again, beside the lists (a block is a few thousand keys)
+                ZK_TRY(arena_alloc(c, 8 * m, (void**)&bk));
+                ZK_TRY(expand_tags(c, tags, cuts, (uint32_t)chunks, a.tag_bits, bk - lohi[0], list[i], 1));
+            }
+            ZK_TRY(sort_keys(c, bk, work + lohi[0], m, a.tag_bits, &res));
+            if (res != bk) ZK_HIP(c, hipMemcpyAsync(bk, res, 8 * m, hipMemcpyDeviceToDevice, c->stream));
             uint64_t u = 0;
             bool ovf = false;
-            ZK_TRY(rle(c, keys + lohi[0], m, work + lohi[0], nullptr, m, &u, pack, &ovf));
+            ZK_TRY(rle(c, bk, m, work + lohi[0], nullptr, m, &u, pack, &ovf));
             if (ovf) { r->flags |= 1; break; }          // (a count beyond the field in such a block: the long way after all)
             ZK_HIP(c, hipMemcpy(nwords + list[i], &u, sizeof(u64), hipMemcpyHostToDevice));
         }

@@ -318,7 +318,9 @@ class Context:
                  "union_sum": 7, "select": 8, "mirror": 9, "intersect": 10, "count_hist": 11, "pass_packed": 12, "sample": 13}
 
     def tune(self, sort_variant=None, pairs_variant=None, short_sort=None, side_div=None, xcd_group=None, comm_chunk=None,
-             early_collapse=None, packed_pairs=None, wide_tiles=None, stream_pass=None, stream_ranges=None):
+             early_collapse=None, packed_pairs=None, wide_tiles=None, stream_pass=None, stream_ranges=None, tag_words=None):
+        if tag_words is not None:
+            self._check(self.lib.zk_tune(self.h, 12, int(tag_words)))
         if stream_pass is not None:
             self._check(self.lib.zk_tune(self.h, 10, int(stream_pass)))
         if stream_ranges is not None:
