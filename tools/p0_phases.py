@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: where wave 0 of a stream_pass0_kernel workgroup spends a tile (in-kernel s_memtime, 100 MHz ticks), and the
-HIP-event times of the histogram and the pass.  usage: p0_phases.py [reads] [stream_pass variant] [K]"""
+HIP-event times of the histogram and the pass; the same for dedupe_kernel per block.  Needs the diagnostic build:
+make -C zotmer_amd/csrc clean && make -C zotmer_amd/csrc CXXFLAGS_EXTRA=-DZK_PHASES (rebuild without it afterwards).  usage: p0_phases.py [reads] [stream_pass variant] [K]"""
 import json, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,14 +14,16 @@ cfg = synth.CONFIGS["config2"]
 ctx = native.Context(0)
 ctx.tune(stream_pass=variant)
 d = ctx.synth_reads(synth.DEFAULT_SEED, 0, reads, cfg["L"], genome=cfg["genome"], sub_thr=synth.frac32(cfg["sub"]), n_thr=synth.frac32(cfg["n"]))
-ctx.kmerize(d, K)
+cap = int(2 * (min(cfg["genome"], reads * cfg["L"]) + reads * cfg["L"] * cfg["sub"] * 22) * 1.25) + (1 << 20)
+outs = (ctx.empty(cap, np.uint64), ctx.empty(cap, np.uint32))
+ctx.kmerize(d, K, out=outs)
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0          # 1: the pass without its stores, 2: the stores of a range's first tile only, repeated
 ranges = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 ctx.tune(stream_pass=variant | (mode << 8), stream_ranges=ranges)
 dbg = ctx.upload(np.zeros(4096 * 16, np.uint64))
 ctx._check(ctx.lib.zk_debug_buffer(ctx.h, dbg.ptr))
 ctx.profile(True)
-ctx.kmerize(d, K)
+ctx.kmerize(d, K, out=outs)
 ctx.sync()
 prof = ctx.profile_read()
 ctx.profile(False)
@@ -33,4 +36,12 @@ per = raw[:, :8].sum(axis=0) / tiles * 10.0          # ns per tile
 out = {"reads": reads, "variant": variant, "mode": mode, "K": K, "ranges": int(len(raw)), "tiles_per_range": float(raw[:, 8].mean()),
        "ns_per_tile": {n: round(float(v), 1) for n, v in zip(names, per)}, "ns_per_tile_total": round(float(per.sum()), 1),
        "hist_stream_ms": prof.get("hist_stream", {}).get("ms"), "pass_stream_ms": prof.get("pass_stream", {}).get("ms")}
+dd = dbg.to_host().reshape(4096, 16).astype(np.float64)[512:512 + 256]          # dedupe_kernel's rows (zk_debug_buffer + 8192 words)
+dd = dd[dd[:, 8] > 0]
+if len(dd):
+    nb = dd[:, 8].sum()
+    names = ["0 clear table", "1 insert keys (+ loads)", "2 drain + barrier", "3 read entries, count byte groups", "4 scan + group", "5 rank + write", "6 barrier"]
+    out["dedupe_cycles_per_block"] = {n: round(float(v), 1) for n, v in zip(names, dd[:, :7].sum(axis=0) / nb)}
+    out["dedupe_blocks"] = int(nb)
+    out["rle_ms"] = prof.get("rle", {}).get("ms")
 print(json.dumps(out))

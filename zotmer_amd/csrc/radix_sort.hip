@@ -979,7 +979,13 @@ struct DedupeArgs {
     u32* bad;           // [bad_cap] blocks whose table filled up: they write nothing here, the host counts them by sorting
     u32* n_bad;
     u32 bad_cap;
+    u64* dbg;           // or null (zk_debug_buffer + 8192 words): [workgroup][16] ticks per phase of a block, summed (tools/p0_phases.py)
 };
+#ifdef ZK_PHASES          // make CXXFLAGS_EXTRA=-DZK_PHASES: the diagnostic build tools/p0_phases.py reads
+#define DD_PHASE(k) do { if (a.dbg) { const u32 now__ = (u32)__builtin_amdgcn_s_memtime(); ph[k] += now__ - tlast; tlast = now__; } } while (0)
+#else
+#define DD_PHASE(k) do { } while (0)
+#endif
 
 // cuts[v] = first index whose key >> tag_bits is >= v, v = 0 .. blocks
 __global__ void dedupe_cuts_kernel(const u64* __restrict__ k, u64 n, int tag_bits, u32 blocks, u64* __restrict__ cuts) {
@@ -1003,7 +1009,7 @@ struct DedupeNext {
 };
 
 template <bool TAG32, bool TAGIN>
-__device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG32>& sm, DedupeNext<DedupeSmem<TAG32>::ITEMS>& st) {
+__device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG32>& sm, DedupeNext<DedupeSmem<TAG32>::ITEMS>& st, u32 (&ph)[8], u32& tlast) {
     using S = DedupeSmem<TAG32>;
     using E = typename S::E;
     constexpr int BLOCK = S::BLOCK, ITEMS = S::ITEMS, TILE = S::TILE, ALL = S::ALL, SPT = S::SPT, NB = S::NB;
@@ -1061,6 +1067,7 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
     for (int q = tid; q < ALL / 4; q += BLOCK) reinterpret_cast<uint4*>(sm.cnt)[q] = make_uint4(0, 0, 0, 0);
     if (tid < NB) { sm.bc[tid] = 0; sm.bfill[tid] = 0; }
     __syncthreads();
+    DD_PHASE(0);          // table cleared
     const u32 nchunk = (u32)__builtin_amdgcn_readfirstlane((int)sm.ticket);
     u64 nlo = 0, nhi = 0;
     if (nchunk < a.chunks) { nlo = a.cuts[nchunk]; nhi = a.cuts[nchunk + 1]; }
@@ -1101,6 +1108,8 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
         }
         nside = 0;
     };
+    // (Measured: the eight compare-and-swaps of a tile issued back to back before any answer is used -- 24.6 ms against 21.3: the
+    // insert is bound by the LDS atomic unit's throughput (two atomics per key, ~47 K per block), not by the round trips.)
     auto insert = [&](u64 k, bool valid) {
         const E e = (E)(k & tmask);
         const u32 h = home(e);
@@ -1129,9 +1138,12 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
         for (int i = 0; i < ITEMS; i++) key[i] = nk[i];
         if (nside > (u32)S::SIDE_KEEP || base + TILE >= hi) drain();
     }
+    DD_PHASE(1);          // keys inserted
     st.chunk = nchunk; st.lo = nlo; st.hi = nhi;
     if (nhi > nlo) load(nlo, nhi, st.key);          // the next block's first tile travels while this one is sorted and written
-    if (__syncthreads_or((int)bad)) {
+    const int any_bad = __syncthreads_or((int)bad);
+    DD_PHASE(2);          // ... every wave done
+    if (any_bad) {
         // the table filled up (a block with more distinct keys than it holds): the block goes on the list of those the host
         // counts by sorting; only when that list is full is the whole run given up
         if (tid == 0) {
@@ -1154,6 +1166,7 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
         if (ec[j]) atomicAdd(&sm.bc[(u32)((u64)et[j] >> bsh) & (NB - 1)], 1u);
     }
     __syncthreads();
+    DD_PHASE(3);          // entries read, byte groups counted
     if (wave == 0) {
         u32 c4[4], sum = 0;
 #pragma unroll
@@ -1178,6 +1191,7 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
         }
     }
     __syncthreads();
+    DD_PHASE(4);          // grouped by top byte
     const u64 hi_part = (u64)chunk << a.tag_bits;          // the bits every key of the block has above its tag
     for (u32 i = (u32)tid; i < total; i += BLOCK) {
         const E mine = sm.keys[i];
@@ -1194,6 +1208,7 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
         }
         a.out[lo + g0 + rank] = (k << a.pack) | (u64)(c > maxc ? 0u : c);
     }
+    DD_PHASE(5);          // ranked and written
 }
 
 // Persistent: one workgroup per CU (the table takes most of its LDS) draws the blocks from a counter -- in order, not strided:
@@ -1216,9 +1231,19 @@ __global__ __launch_bounds__(1024, 4) void dedupe_kernel(DedupeArgs a) {
         else st.key[i] = g < st.hi ? a.kin[g] : ~0ull;
     }
     __syncthreads();          // the ticket word is free again
+    u32 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u32 tlast = a.dbg ? (u32)__builtin_amdgcn_s_memtime() : 0u;
+    (void)tlast;
+    u32 nblk = 0;
     while (st.chunk < a.chunks) {
-        dedupe_block<TAG32, TAGIN>(a, sm, st);          // leaves the next block in st
+        dedupe_block<TAG32, TAGIN>(a, sm, st, ph, tlast);          // leaves the next block in st
         __syncthreads();          // the table and the ticket word are free again
+        DD_PHASE(6);
+        nblk++;
+    }
+    if (a.dbg && threadIdx.x == 0) {
+        for (int k = 0; k < 8; k++) a.dbg[(u64)blockIdx.x * 16 + k] = ph[k];
+        a.dbg[(u64)blockIdx.x * 16 + 8] = nblk;
     }
 }
 
@@ -2189,6 +2214,7 @@ int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int
     ZK_TRY(arena_alloc(c, sizeof(u32) * bad_cap, (void**)&a.bad));
     a.bad_cap = bad_cap;
     a.n_bad = (u32*)(c->d_scalars + 31);
+    a.dbg = c->dbg ? c->dbg + 8192 : nullptr;
     // the mirror sort can group by 6 more bits if the blocks say how their entries split on them: 64 counts per block, when the
     // workspace has the room (and the finer grouping's tables after it: dedupe_finish)
     // ... leaving what the sorts and the union after it need (their tables are a few bytes per thousand keys)

@@ -363,7 +363,11 @@ struct P0Args {
     u64* dbg;             // or null (zk_debug_buffer): [ranges][16] time (s_memtime ticks) wave 0 of the range spent per phase, summed over its tiles
 };
 // phase accounting for tools/p0_phases.py: a handful of scalar instructions per tile when off
+#ifdef ZK_PHASES          // make CXXFLAGS_EXTRA=-DZK_PHASES: the diagnostic build
 #define P0_PHASE(k) do { if (a.dbg) { const u32 now__ = (u32)__builtin_amdgcn_s_memtime(); ph[k] += now__ - tlast; tlast = now__; } } while (0)
+#else
+#define P0_PHASE(k) do { } while (0)
+#endif
 
 // inclusive prefix sum over the 64 lanes with DPP moves (row shifts, then the two row broadcasts of gfx9): no LDS round trips
 __device__ __forceinline__ u32 wave_incl_scan_dpp(u32 v) {
@@ -454,6 +458,7 @@ __global__ __launch_bounds__(P0_BLOCK, 4) void stream_pass0_kernel(P0Args a) {
     __syncthreads();
     u32 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     u32 tlast = a.dbg ? (u32)__builtin_amdgcn_s_memtime() : 0;
+    (void)tlast;
     // Units [first, end) of the list out: G / 2 lanes per unit, two keys (16 bytes) per lane, four units of a lane group in flight
     // (their LDS reads are issued together; the values are pinned or the compiler moves each unit's reads back under its own branch).
     struct __attribute__((packed, aligned(8))) Key2 { u64 a, b; };
