@@ -170,7 +170,8 @@ struct SHistArgs {
 // hi(min(x, xb)) == min(hi x, hi xb) -- and the low words are never built.
 // TWO: the plan has exactly two passes (the usual one: two passes over the top bits, then the block dedupe), their digits in
 // scalar registers; otherwise the passes are walked through a table in LDS.
-template <bool HI, bool TWO>
+// CANON_T: 1 = the mode is known to be ZK_KEYS_CANONICAL when the kernel is compiled (the usual launch), -1 = read from the arguments.
+template <bool HI, bool TWO, int CANON_T = -1>
 __global__ __launch_bounds__(SH_BLOCK, 4) void stream_hist_kernel(SHistArgs h) {
     extern __shared__ u32 bins[];
     __shared__ TileImage<SH_TILE> img;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(SH_BLOCK, 4) void stream_hist_kernel(SHistArgs h) {
     const int np = h.plan.passes;
     const u64 mask = ~0ull >> (64 - 2 * K);
     const u32 mlo = (u32)mask, mhi = (u32)(mask >> 32);
-    const bool canon = h.mode == ZK_KEYS_CANONICAL;
+    const bool canon = CANON_T == 1 ? true : h.mode == ZK_KEYS_CANONICAL;
     // TWO: the two digits
     const u32 sh0 = (u32)h.plan.shift[0] - (HI ? 32u : 0u), sh1 = (u32)h.plan.shift[1] - (HI ? 32u : 0u);
     const u32 dm0 = (1u << h.plan.bits[0]) - 1u, dm1 = (1u << h.plan.bits[1]) - 1u;
@@ -219,28 +220,39 @@ __global__ __launch_bounds__(SH_BLOCK, 4) void stream_hist_kernel(SHistArgs h) {
     for (u32 j = sp; j < ntile; j += h.split) {
         const u64 off = B + (u64)j * SH_TILE + 16ull * tid;
         const bool mine = off < E;          // chunks past the range's end belong to the next range
-        if (rec) {
-            if (mine) {
-                const u32 w4[4] = {q0.x, q0.y, q0.z, q0.w};
-                const int sep = (int)(rec - 1u) - (int)m;
-                const bool expect = sep >= 0 && sep < 16 && off + (u64)sep < h.n_bytes;
-                bool bad = false;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const u32 x = w4[q] ^ 0x0a0a0a0au;
-                    const u32 t = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
-                    nl_count += (u32)__popc(t);
-                    const u32 want = (expect && (sep >> 2) == q) ? (0x80u << (8 * (sep & 3))) : 0u;
-                    bad |= (t != want);
-                }
-                bad_count += bad ? 1u : 0u;
-            }
-            m += step_m;
-            if (m >= rec) m -= rec;
-        }
         {
             u32 cc, vv;
             encode_swar16(q0, cc, vv);
+            if (rec) {
+                if (mine) {
+                    // Is this chunk's only newline the separator it should have?  If every byte but that one is a base (the usual
+                    // chunk), only the separator's byte needs a look; a chunk with any other non-base (an N, the stream's end) is
+                    // checked byte by byte.
+                    const int sep = (int)(rec - 1u) - (int)m;
+                    const bool expect = sep >= 0 && sep < 16 && off + (u64)sep < h.n_bytes;
+                    const u32 sepbit = expect ? (0x8000u >> (sep & 15)) : 0u;
+                    if ((vv | sepbit) == 0xffffu) {
+                        const u32 wsel = (sep & 12) == 0 ? q0.x : (sep & 12) == 4 ? q0.y : (sep & 12) == 8 ? q0.z : q0.w;
+                        const bool isnl = ((wsel >> (8 * (sep & 3))) & 0xffu) == 0x0au;
+                        nl_count += (expect && isnl) ? 1u : 0u;
+                        bad_count += (expect && !isnl) ? 1u : 0u;
+                    } else {
+                        const u32 w4[4] = {q0.x, q0.y, q0.z, q0.w};
+                        bool bad = false;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const u32 x = w4[q] ^ 0x0a0a0a0au;
+                            const u32 t = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);
+                            nl_count += (u32)__popc(t);
+                            const u32 want = (expect && (sep >> 2) == q) ? (0x80u << (8 * (sep & 3))) : 0u;
+                            bad |= (t != want);
+                        }
+                        bad_count += bad ? 1u : 0u;
+                    }
+                }
+                m += step_m;
+                if (m >= rec) m -= rec;
+            }
             img.codes[tid] = cc; img.valid[tid] = vv;
             if (mine && h.gcodes) { h.gcodes[off >> 4] = cc; h.gvalid[off >> 4] = (u16)vv; }
             if (tid < 3) {
@@ -268,6 +280,7 @@ __global__ __launch_bounds__(SH_BLOCK, 4) void stream_hist_kernel(SHistArgs h) {
             a2 += (u32)__popc(hl & ~ll) + (u32)__popc(~hf & lf);
             a3 += (u32)__popc(hl & ll) + (u32)__popc(Vs & ~hf & ~lf);
         }
+        u32 hits = 0;          // windows whose key belongs to the set-aside blocks
 #pragma unroll
         for (int i = 0; i < SH_NW; i++) {
             const u32 inc = (V16 >> (15 - i)) & 1u;
@@ -289,15 +302,22 @@ __global__ __launch_bounds__(SH_BLOCK, 4) void stream_hist_kernel(SHistArgs h) {
             } else {
                 for (int p = 0; p < np; p++) atomicAdd(&bins[pbase[p] + ((u32)(kd >> pshift[p]) & pmask[p])], inc);
             }
-            if (h.sample) {
-                const bool hit = (kd >> ssh) == sval && inc;
-                if (__builtin_amdgcn_ballot_w64(hit)) {          // rare: four blocks of 2^18
-                    if (hit) {
-                        const u64 x = (((u64)ww.xhi(i) << 32) | ww.xlo(i)) & mask, xb = (((u64)ww.bhi(i) << 32) | ww.blo(i)) & mask;
-                        const u64 kk = canon ? (x < xb ? x : xb) : x;
-                        const u32 at = atomicAdd(h.sample_n, 1u);
-                        if (at < h.sample_cap) h.sample[at] = kk;
-                    }
+            if constexpr (HI) {
+                if (h.sample) hits |= ((kd >> ssh) == sval ? 1u : 0u) << (15 - i);          // looked at once per tile, below
+            } else if (h.sample && inc && (kd >> ssh) == sval) {
+                const u32 at = atomicAdd(h.sample_n, 1u);
+                if (at < h.sample_cap) h.sample[at] = kd;
+            }
+        }
+        hits &= V16;
+        if (HI && hits) {          // rare (four blocks of 2^18): the set-aside keys are made in full and appended
+#pragma unroll
+            for (int i = 0; i < SH_NW; i++) {
+                if ((hits >> (15 - i)) & 1u) {
+                    const u64 x = (((u64)ww.xhi(i) << 32) | ww.xlo(i)) & mask, xb = (((u64)ww.bhi(i) << 32) | ww.blo(i)) & mask;
+                    const u64 kk = canon ? (x < xb ? x : xb) : x;
+                    const u32 at = atomicAdd(h.sample_n, 1u);
+                    if (at < h.sample_cap) h.sample[at] = kk;
                 }
             }
         }
@@ -679,7 +699,8 @@ int stream_hist(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, 
     const u32 grid = h.ranges * h.split;
     prof_begin(c, ZK_PROF_HIST_STREAM, n_bytes);
     const bool two = plan.passes == 2;
-    if (hi && two) hipLaunchKernelGGL((stream_hist_kernel<true, true>), dim3(grid), dim3(SH_BLOCK), nb * sizeof(u32), c->stream, h);
+    if (hi && two && mode == ZK_KEYS_CANONICAL) hipLaunchKernelGGL((stream_hist_kernel<true, true, 1>), dim3(grid), dim3(SH_BLOCK), nb * sizeof(u32), c->stream, h);
+    else if (hi && two) hipLaunchKernelGGL((stream_hist_kernel<true, true>), dim3(grid), dim3(SH_BLOCK), nb * sizeof(u32), c->stream, h);
     else if (hi) hipLaunchKernelGGL((stream_hist_kernel<true, false>), dim3(grid), dim3(SH_BLOCK), nb * sizeof(u32), c->stream, h);
     else if (two) hipLaunchKernelGGL((stream_hist_kernel<false, true>), dim3(grid), dim3(SH_BLOCK), nb * sizeof(u32), c->stream, h);
     else hipLaunchKernelGGL((stream_hist_kernel<false, false>), dim3(grid), dim3(SH_BLOCK), nb * sizeof(u32), c->stream, h);
