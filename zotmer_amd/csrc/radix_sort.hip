@@ -2025,7 +2025,7 @@ struct Sorter {
             const bool uniform = first_nl < 0x7fffffffull && src.n_bytes % (first_nl + 1) == 0 && bad == 0 && nl == src.n_bytes / (first_nl + 1);
             ZK_TRY(stream_pass0(c, src.n_bytes, src.K, src.mode, plan.shift[0], plan.bits[0], ghist, srows, first_nl, uniform, buf_a, n,
                                 c->stream_pass));
-            if (c->stream_pass >> 8) { *n_keys = 0; return ZK_OK; }          // measurement modes of the pass (tools/p0_phases.py): its output is not for use
+            if (c->stream_pass >> 8) { *n_keys = 0; return ZK_OK; }          // measurement modes of the pass (diagnostic build, tools/p0_phases.py): nothing is counted
         } else
         if constexpr (C::PIPE && C::ITEMS == 16 && PipeSmem<C>::IMG_FITS && C::BLOCK <= 512) {
             // Uniform records (checked by the histogram kernel: the only newlines are one every `rec` bytes): tiles follow

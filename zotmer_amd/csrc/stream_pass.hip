@@ -379,13 +379,15 @@ struct P0Args {
     u64 n;                // keys in all: nothing is ever stored at or beyond it
     u32* err;
     int split_stores;     // 1: a tile's units leave in two bursts (see the kernel)
-    int dbg_mode;         // measurements only (results are wrong): 1 = no stores, 2 = after a range's first tile only the stores (its keys again and again)
+    int dbg_mode;         // diagnostic build (-DZK_PHASES) only, measurements (results are wrong): 1 = no stores, 2 = after a range's first tile only the stores (its keys again and again)
     u64* dbg;             // or null (zk_debug_buffer): [ranges][16] time (s_memtime ticks) wave 0 of the range spent per phase, summed over its tiles
 };
 // phase accounting for tools/p0_phases.py: a handful of scalar instructions per tile when off
-#ifdef ZK_PHASES          // make CXXFLAGS_EXTRA=-DZK_PHASES: the diagnostic build
+#ifdef ZK_PHASES          // make CXXFLAGS_EXTRA=-DZK_PHASES: the diagnostic build (phase accounting and the measurement modes)
+#define P0_MODE (a.dbg_mode)
 #define P0_PHASE(k) do { if (a.dbg) { const u32 now__ = (u32)__builtin_amdgcn_s_memtime(); ph[k] += now__ - tlast; tlast = now__; } } while (0)
 #else
+#define P0_MODE 0
 #define P0_PHASE(k) do { } while (0)
 #endif
 
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(P0_BLOCK, 4) void stream_pass0_kernel(P0Args a) {
                 const u32 u = base + g * GROUPS + g0;
                 const u32 len1 = (e4[g] >> 14) & 15u;          // keys - 1
                 u64* dst = a.kout + (b4[g] + (e4[g] & 0x3fffu) + j);          // (inside the digit's piece by construction)
-                if (u < end && a.dbg_mode != 1) {
+                if (u < end && P0_MODE != 1) {
                     if (j < len1) { Key2 v; v.a = k4[g]; v.b = l4[g]; *reinterpret_cast<Key2*>(dst) = v; }
                     else if (j == len1) *dst = k4[g];
                 }
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(P0_BLOCK, 4) void stream_pass0_kernel(P0Args a) {
     for (u32 t = 0; t < ntile; t++) {
         const u64 T0 = B + (u64)t * tile_bytes;
         const bool last = t + 1 == ntile;
-        if (a.dbg_mode == 2 && t > 1) {
+        if (P0_MODE == 2 && t > 1) {
             // measurement: the first tile's units again, further down the output
             __syncthreads();
             sm.gbase[tid] += flen_dbg;
@@ -641,7 +643,7 @@ __global__ __launch_bounds__(P0_BLOCK, 4) void stream_pass0_kernel(P0Args a) {
         // until that tile's scan and park): two bursts of stores per tile instead of one, the other workgroup of the CU fills the gaps
         {
             const u32 nunits = sm.nunits;
-            const u32 half = (a.dbg_mode == 2 || !a.split_stores) ? nunits : (nunits / 2 + 127u) & ~127u;
+            const u32 half = (P0_MODE == 2 || !a.split_stores) ? nunits : (nunits / 2 + 127u) & ~127u;
             store_units(0, half < nunits ? half : nunits, std::integral_constant<int, 4>());
             held = half < nunits ? half : nunits; held_end = nunits;
         }
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(P0_BLOCK, 4) void stream_pass0_kernel(P0Args a) {
         for (int k = 0; k < 8; k++) a.dbg[(u64)w * 16 + k] = (u64)ph[k];
         a.dbg[(u64)w * 16 + 8] = ntile;
     }
-    if (a.dbg_mode) return;
+    if (P0_MODE) return;
     if (bad || ((u32)tid < radix && (F != Fend || nck != 0))) atomicOr(a.err, ZK_DERR_MISMATCH);
 }
 
