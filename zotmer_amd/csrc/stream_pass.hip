@@ -382,7 +382,7 @@ struct P0Args {
     int dbg_mode;         // diagnostic build (-DZK_PHASES) only, measurements (results are wrong): 1 = no stores, 2 = after a range's first tile only the stores (its keys again and again)
     u64* dbg;             // or null (zk_debug_buffer): [ranges][16] time (s_memtime ticks) wave 0 of the range spent per phase, summed over its tiles
 };
-// phase accounting for tools/p0_phases.py: a handful of scalar instructions per tile when off
+// phase accounting and measurement modes for tools/p0_phases.py: compiled in only with -DZK_PHASES
 #ifdef ZK_PHASES          // make CXXFLAGS_EXTRA=-DZK_PHASES: the diagnostic build (phase accounting and the measurement modes)
 #define P0_MODE (a.dbg_mode)
 #define P0_PHASE(k) do { if (a.dbg) { const u32 now__ = (u32)__builtin_amdgcn_s_memtime(); ph[k] += now__ - tlast; tlast = now__; } } while (0)
