@@ -81,6 +81,13 @@ int zk_upload_async(zk_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 #define ZK_TUNE_STREAM_RANGES 11 /* ... the number of ranges the stream is cut into, one workgroup each (0 = one per CU, the default; <= 4096) */
 #define ZK_TUNE_TAG_WORDS 12     /* zk_kmerize: 1 (default) = the pass before the block dedupe writes 32-bit tags instead of whole keys when the key bits
                                   * below the blocks fit (K <= 25 after two passes); 0 = whole keys */
+#define ZK_TUNE_DEDUPE_VARIANT 13 /* the block dedupe of zk_kmerize at <= 32 key bits below the blocks: 0 (default) = dedupe2_kernel, two 512-thread
+                                  * workgroups per CU; 2 = the same with a plain read before the compare-and-swap;
+                                  * -1 = dedupe_kernel alone (one workgroup per CU, the table of rounds 2 and 3) */
+#define ZK_TUNE_DEDUPE_LIMIT 14  /* ... dedupe2_kernel declines blocks of this many keys or more (they are counted by dedupe_kernel afterwards);
+                                  * 65536 (default, the most its 16-bit counts allow); tests lower it to reach the second kernel */
+#define ZK_TUNE_DEDUPE_BITS 15   /* tests: zk_kmerize takes the block dedupe with this many block bits (a whole number of 9-bit passes, e.g. 18)
+                                  * whatever the size of the input, so that small oracle-checked inputs run two passes, tags and tiny blocks; 0 = by size (default) */
 #define ZK_TUNE_COMM_CHUNK 6     /* zk_all_to_all_v: bytes per message and round (0 = 256 MiB, the default) */
 int zk_tune(zk_ctx* ctx, int what, int value);
 

@@ -330,6 +330,38 @@ def test_kmerize_early_collapse_paths_agree(ctx, K):
             ctx.tune(early_collapse=1, packed_pairs=1)
 
 
+@pytest.mark.parametrize("K", [16, 20, 25, 27])
+def test_kmerize_forced_block_dedupe(ctx, K):
+    """The plan of a 50 M-read batch -- two passes over the top 18 bits, the second one writing 32-bit tags where the bits below fit
+    (K <= 25), the blocks of equal top bits counted in LDS tables -- forced (ZK_TUNE_DEDUPE_BITS) on inputs small enough for the
+    oracle, where nothing else reaches it: tags against whole keys (tag_words), dedupe2_kernel (two workgroups per CU; with and
+    without the plain read before the swap) against dedupe_kernel alone, the second chance of the blocks dedupe2_kernel declines
+    (dedupe_limit lowered so that ordinary blocks count as too large), a block with more distinct keys than any table holds (sorted
+    by the host, from tags), counts beyond the packed field, and an input without repeats (declined after the passes: the keys are
+    made again from their tags and sorted the long way).  18 block bits on ~1 M keys: blocks of a few keys, many of them empty."""
+    rng = np.random.default_rng(300 + K)
+    deep = synth.read_strings(31, 0, 6000, 150, genome=12000, sub_thr=synth.frac32(0.004), n_thr=synth.frac32(0.001))
+    flat = synth.read_strings(32, 0, 3000, 150, genome=0)
+    # 14 000 distinct k-mers that share their first nine bases (one block of the 18-bit plan), in an input that repeats its k-mers
+    dense = deep + ["AAAAAAAAA" + "".join(rng.choice(list("ACGT"), size=K - 9)) for _ in range(14000)]
+    heavy = deep[:1500] + ["A" * 150] * 400 + ["AC" * 75] * 300
+    # one block with 70 000 keys (more than a 16-bit count may see) of a few hundred distinct k-mers
+    big = deep[:1000] + ["AAAAAAAAA" + "".join(rng.choice(list("ACGT"), size=K - 9)) for _ in range(300)] * 240
+    try:
+        for name, reads in (("deep", deep), ("flat", flat), ("mixed", deep[:2000] + flat[:2000]), ("dense_block", dense), ("heavy_counts", heavy),
+                            ("big_block", big)):
+            want = zo.kmerize(K, reads)
+            d = ctx.upload_stream(stream_of(reads))
+            for tag_words, variant, limit in ((1, 0, 65536), (0, 0, 65536), (1, 2, 65536), (1, -1, 65536), (1, 0, 6), (0, 2, 6)):
+                ctx.tune(dedupe_bits=18, tag_words=tag_words, dedupe_variant=variant, dedupe_limit=limit)
+                k, c, st = ctx.kmerize(d, K)
+                assert np.array_equal(k.to_host(), want["kmers"]), (name, tag_words, variant, limit)
+                assert np.array_equal(c.to_host(), want["counts"]), (name, tag_words, variant, limit)
+                assert list(st.acgt) == want["acgt"] and st.n_unique == len(want["kmers"])
+    finally:
+        ctx.tune(dedupe_bits=0, tag_words=1, dedupe_variant=0, dedupe_limit=65536)
+
+
 @pytest.mark.parametrize("K", [4, 12, 24, 25, 31, 32])
 def test_kmerize_canonical_only_and_mirror_expand(ctx, K):
     """zk_kmerize(ZK_KMERIZE_CANONICAL_ONLY) = the counted list of c = min(x, rc x); zk_mirror_expand of it = zk_kmerize.

@@ -314,7 +314,9 @@ int zk_tune(zk_ctx* c, int what, int value) {
     if (what == ZK_TUNE_COMM_CHUNK) { c->comm_chunk_bytes = value > 0 ? (uint64_t)value : 0; return ZK_OK; }
     if (what == ZK_TUNE_STREAM_PASS) { c->stream_pass = value < 0 ? 0 : value; return ZK_OK; }
     if (what == ZK_TUNE_TAG_WORDS) { c->tag_words = value ? 1 : 0; return ZK_OK; }
-    if (what == ZK_TUNE_TAG_WORDS) { c->tag_words = value ? 1 : 0; return ZK_OK; }
+    if (what == ZK_TUNE_DEDUPE_VARIANT) { c->dedupe_variant = value < 0 ? -1 : (value & 3); return ZK_OK; }
+    if (what == ZK_TUNE_DEDUPE_BITS) { c->dedupe_bits = value < 0 ? 0 : value; return ZK_OK; }
+    if (what == ZK_TUNE_DEDUPE_LIMIT) { c->dedupe_limit = value < 1 ? 1 : (value > 65536 ? 65536 : value); return ZK_OK; }
     if (what == ZK_TUNE_STREAM_RANGES) { c->stream_ranges = value < 0 ? 0 : (value > 4096 ? 4096 : value); return ZK_OK; }
     if (what == ZK_TUNE_XCD_GROUP) {
         if (value < 0 || value > 32 || (value & (value - 1))) return fail(c, ZK_EINVAL, "xcd group must be 0 or a power of two <= 32");

@@ -265,6 +265,11 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
         const int b = rb * passes;
         if (b < fused_bit + rb && b + rb / 2 < 2 * K && b <= 24 && (n_bytes >> b) >= 2048) dedupe_bit = b;
     }
+    // tests (ZK_TUNE_DEDUPE_BITS): the same plan forced on an input of any size -- two passes, tags and blocks of a handful of keys
+    // on inputs small enough for the oracle
+    if (!both && c->early_collapse == 1 && c->dedupe_bits > 0 && c->packed_pairs && pack_bits_for(K) && c->dedupe_bits % rb == 0 &&
+        c->dedupe_bits + rb / 2 < 2 * K && c->dedupe_bits <= 24)
+        dedupe_bit = c->dedupe_bits;
     uint64_t n = 0;
     u64* sorted = nullptr;
     bool presampled = false;
@@ -540,7 +545,7 @@ int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, dou
     arena_reset(c);
     // histograms, merge-path partitions, the mirror group tables (4 MB); from 2^29 stream bytes on (block dedupe with 2^18 blocks) the
     // blocks' tables as well: bounds, sizes, and the 2^24 run places of the mirror grouping (336 MB)
-    const uint64_t slack = (16 << 20) + cap_keys / 16 + (n_bytes >= (1ull << 29) ? (384ull << 20) : 0);          // (+ the block starts of the tag path: 2 MB)
+    const uint64_t slack = (16 << 20) + cap_keys / 16 + ((n_bytes >= (1ull << 29) || c->dedupe_bits >= 18) ? (384ull << 20) : 0);          // (+ the block starts of the tag path: 2 MB; the list of declined blocks: 1 MB)
     ZK_TRY(arena_require(c, 16 * cap_keys + slack, 16 * cap_keys + slack));
     u64 *buf_a, *buf_b;
     ZK_TRY(arena_alloc(c, 8 * cap_keys, (void**)&buf_a));

@@ -24,6 +24,7 @@
 // measurements on MI355X).
 #include "internal.hpp"
 #include "encode_tile.hpp"
+#include "dedupe.hpp"
 
 namespace zk {
 
@@ -960,33 +961,6 @@ struct DedupeSmem {
     u32 ticket;
 };
 
-struct DedupeArgs {
-    const u64* kin;
-    const u32* tin;     // or: the keys' low 32 bits only (TAGIN; the bits above are the block's number)
-    u64 n;
-    const u64* cuts;    // [chunks + 1]: chunk v = the block of keys whose top bits are v
-    u64* out;           // block v writes its words from out + cuts[v] on; dedupe_unpack_kernel closes the gaps
-    u64* nwords;        // [chunks] words of block v
-    int tag_bits;       // key bits below the block bits
-    int pack;
-    u32* flags;         // |= 1: a table filled up, |= 2: some count went to the side list
-    u32* counter;       // the next block to take
-    u64* big;           // (key, count) pairs whose count does not fit `pack` bits
-    u32* n_big;
-    u32 big_cap;
-    u32 chunks;
-    u32* sub;           // or null: [chunks][64] entries of block v whose tag starts with the 6 bits j (the mirror sort groups by them)
-    u32* bad;           // [bad_cap] blocks whose table filled up: they write nothing here, the host counts them by sorting
-    u32* n_bad;
-    u32 bad_cap;
-    u64* dbg;           // or null (zk_debug_buffer + 8192 words): [workgroup][16] ticks per phase of a block, summed (tools/p0_phases.py)
-};
-#ifdef ZK_PHASES          // make CXXFLAGS_EXTRA=-DZK_PHASES: the diagnostic build tools/p0_phases.py reads
-#define DD_PHASE(k) do { if (a.dbg) { const u32 now__ = (u32)__builtin_amdgcn_s_memtime(); ph[k] += now__ - tlast; tlast = now__; } } while (0)
-#else
-#define DD_PHASE(k) do { } while (0)
-#endif
-
 // cuts[v] = first index whose key >> tag_bits is >= v, v = 0 .. blocks
 __global__ void dedupe_cuts_kernel(const u64* __restrict__ k, u64 n, int tag_bits, u32 blocks, u64* __restrict__ cuts) {
     const u32 v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -999,8 +973,11 @@ __global__ void dedupe_cuts_kernel(const u64* __restrict__ k, u64 n, int tag_bit
     cuts[v] = lo;
 }
 
-// what a workgroup carries from one block to the next: the block it is about to count, with the first tile of its keys already
-// asked for -- the ticket, the bounds and those keys travel while the previous block is being sorted and written
+// ticket -> block: the blocks in order, or (second chance of the blocks dedupe2_kernel declined) the ones on a list
+__device__ __forceinline__ u32 dedupe_block_of(const DedupeArgs& a, u32 ticket) { return a.list ? a.list[ticket] : ticket; }
+
+// what a workgroup carries from one block to the next: the block it is about to count (its ticket), with the first tile of its keys
+// already asked for -- the ticket, the bounds and those keys travel while the previous block is being sorted and written
 template <int ITEMS>
 struct DedupeNext {
     u32 chunk;
@@ -1016,7 +993,7 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
     constexpr E EMPTY = (E)~(E)0;            // no entry.  A 64-bit tag never has all its bits set; a 32-bit one may: see `home`
     constexpr u32 HS = TAG32 ? ALL - 1 : ALL;          // ... then the last entry belongs to the all-ones tag alone
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const u32 chunk = st.chunk;
+    const u32 chunk = dedupe_block_of(a, st.chunk);
     const u64 lo = st.lo, hi = st.hi;
     const u32 maxc = (1u << a.pack) - 1u;
     // whole tiles: one address, constant offsets; the cut last tile: per-key bounds
@@ -1059,7 +1036,7 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
         __syncthreads();
         st.chunk = (u32)__builtin_amdgcn_readfirstlane((int)sm.ticket);
         st.lo = st.hi = 0;
-        if (st.chunk < a.chunks) { st.lo = a.cuts[st.chunk]; st.hi = a.cuts[st.chunk + 1]; }
+        if (st.chunk < a.chunks) { const u32 nb = dedupe_block_of(a, st.chunk); st.lo = a.cuts[nb]; st.hi = a.cuts[nb + 1]; }
         if (st.hi > st.lo) load(st.lo, st.hi, st.key);
         return;
     }
@@ -1070,7 +1047,7 @@ __device__ __forceinline__ void dedupe_block(const DedupeArgs& a, DedupeSmem<TAG
     DD_PHASE(0);          // table cleared
     const u32 nchunk = (u32)__builtin_amdgcn_readfirstlane((int)sm.ticket);
     u64 nlo = 0, nhi = 0;
-    if (nchunk < a.chunks) { nlo = a.cuts[nchunk]; nhi = a.cuts[nchunk + 1]; }
+    if (nchunk < a.chunks) { const u32 nb = dedupe_block_of(a, nchunk); nlo = a.cuts[nb]; nhi = a.cuts[nb + 1]; }
     u32 bad = 0;
     // The kernel is bound by its instruction count (188 per key with several keys probing at once, 88 with one tight probing
     // loop per key -- a loop runs as long as the unluckiest of its 64 lanes).  So the common case has NO loop and no branch:
@@ -1223,7 +1200,7 @@ __global__ __launch_bounds__(1024, 4) void dedupe_kernel(DedupeArgs a) {
     __syncthreads();
     st.chunk = (u32)__builtin_amdgcn_readfirstlane((int)sm.ticket);
     st.lo = st.hi = 0;
-    if (st.chunk < a.chunks) { st.lo = a.cuts[st.chunk]; st.hi = a.cuts[st.chunk + 1]; }
+    if (st.chunk < a.chunks) { const u32 nb = dedupe_block_of(a, st.chunk); st.lo = a.cuts[nb]; st.hi = a.cuts[nb + 1]; }
 #pragma unroll
     for (int i = 0; i < S::ITEMS; i++) {
         const u64 g = st.lo + (u64)i * S::BLOCK + threadIdx.x;
@@ -2221,16 +2198,38 @@ int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int
     if (!max_chunks && a.tag_bits >= 14 && c->arena_size - c->arena_off > 64ull * chunks * (4 + 8 + 8) + (32ull << 20) + n / 16)
         ZK_TRY(arena_alloc(c, sizeof(u32) * 64 * chunks, (void**)&a.sub));
     ZK_HIP(c, hipMemsetAsync(c->d_scalars + 27, 0, 5 * sizeof(u64), c->stream));
-    prof_begin(c, ZK_PROF_RLE, 8 * n);
-    const u32 grid = chunks < (uint64_t)c->num_cus ? (u32)chunks : (u32)c->num_cus;
-    if (tags) hipLaunchKernelGGL((dedupe_kernel<true, true>), dim3(grid), dim3(1024), 0, c->stream, a);
-    else if (a.tag_bits <= 32) hipLaunchKernelGGL((dedupe_kernel<true, false>), dim3(grid), dim3(1024), 0, c->stream, a);
-    else hipLaunchKernelGGL((dedupe_kernel<false, false>), dim3(grid), dim3(1024), 0, c->stream, a);
+    // algorithmic bytes: every key read once (a 32-bit tag, or the whole key), one word written per distinct key -- the words are not
+    // counted yet when the launch is timed; the caller's n_out says how many (bench.py adds 8 bytes for each)
+    prof_begin(c, ZK_PROF_RLE, (tags ? 4 : 8) * n);
+    auto launch_one_per_cu = [&](const DedupeArgs& d) {
+        const u32 grid = d.chunks < (u32)c->num_cus ? d.chunks : (u32)c->num_cus;
+        if (tags) hipLaunchKernelGGL((dedupe_kernel<true, true>), dim3(grid), dim3(1024), 0, c->stream, d);
+        else if (d.tag_bits <= 32) hipLaunchKernelGGL((dedupe_kernel<true, false>), dim3(grid), dim3(1024), 0, c->stream, d);
+        else hipLaunchKernelGGL((dedupe_kernel<false, false>), dim3(grid), dim3(1024), 0, c->stream, d);
+    };
+    const bool two_per_cu = a.tag_bits <= 32 && c->dedupe_variant >= 0;
+    if (two_per_cu) {
+        ZK_TRY(arena_alloc(c, sizeof(u32) * chunks, (void**)&a.retry));
+        a.n_retry = (u32*)(c->d_scalars + 28);
+        a.limit = (u32)c->dedupe_limit;
+        ZK_TRY(launch_dedupe2(c, a, tags != nullptr, c->dedupe_variant));
+    } else launch_one_per_cu(a);
     prof_end(c);
     ZK_HIP(c, hipGetLastError());
     ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 27, c->d_scalars + 27, 5 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 32, cuts + chunks, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     ZK_TRY(check_device_error(c));
+    if (two_per_cu && (uint32_t)c->h_scalars[28]) {
+        // the blocks dedupe2_kernel declined (65 536 keys or more; a table that filled up): dedupe_kernel's table is larger and its
+        // counts are 32 bits wide -- what it declines too goes on the list the host counts by sorting
+        DedupeArgs d = a;
+        d.list = a.retry; d.chunks = (uint32_t)c->h_scalars[28]; d.retry = nullptr; d.n_retry = nullptr;
+        ZK_HIP(c, hipMemsetAsync(a.counter, 0, sizeof(u32), c->stream));
+        launch_one_per_cu(d);
+        ZK_HIP(c, hipGetLastError());
+        ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 27, c->d_scalars + 27, 5 * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        ZK_TRY(check_device_error(c));
+    }
     r->flags = (uint32_t)c->h_scalars[27];
     r->n_big = (uint32_t)c->h_scalars[30];
     if (r->n_big > big_cap) r->flags |= 1;          // more counts beyond the field than the side list holds: the long way

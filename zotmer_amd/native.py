@@ -318,7 +318,14 @@ class Context:
                  "union_sum": 7, "select": 8, "mirror": 9, "intersect": 10, "count_hist": 11, "pass_packed": 12, "sample": 13}
 
     def tune(self, sort_variant=None, pairs_variant=None, short_sort=None, side_div=None, xcd_group=None, comm_chunk=None,
-             early_collapse=None, packed_pairs=None, wide_tiles=None, stream_pass=None, stream_ranges=None, tag_words=None):
+             early_collapse=None, packed_pairs=None, wide_tiles=None, stream_pass=None, stream_ranges=None, tag_words=None,
+             dedupe_variant=None, dedupe_limit=None, dedupe_bits=None):
+        if dedupe_bits is not None:
+            self._check(self.lib.zk_tune(self.h, 15, int(dedupe_bits)))
+        if dedupe_variant is not None:
+            self._check(self.lib.zk_tune(self.h, 13, int(dedupe_variant)))
+        if dedupe_limit is not None:
+            self._check(self.lib.zk_tune(self.h, 14, int(dedupe_limit)))
         if tag_words is not None:
             self._check(self.lib.zk_tune(self.h, 12, int(tag_words)))
         if stream_pass is not None:
