@@ -82,7 +82,7 @@ int zk_upload_async(zk_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 #define ZK_TUNE_TAG_WORDS 12     /* zk_kmerize: 1 (default) = the pass before the block dedupe writes 32-bit tags instead of whole keys when the key bits
                                   * below the blocks fit (K <= 25 after two passes); 0 = whole keys */
 #define ZK_TUNE_DEDUPE_VARIANT 13 /* the block dedupe of zk_kmerize at <= 32 key bits below the blocks: 0 (default) = dedupe2_kernel, two 512-thread
-                                  * workgroups per CU; 2 = the same with a plain read before the compare-and-swap;
+                                  * workgroups per CU; 1 / 2 = one / two compare-and-swaps in flight per thread instead of four;
                                   * -1 = dedupe_kernel alone (one workgroup per CU, the table of rounds 2 and 3) */
 #define ZK_TUNE_DEDUPE_LIMIT 14  /* ... dedupe2_kernel declines blocks of this many keys or more (they are counted by dedupe_kernel afterwards);
                                   * 65536 (default, the most its 16-bit counts allow); tests lower it to reach the second kernel */

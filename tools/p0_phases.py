@@ -13,6 +13,8 @@ K = int(sys.argv[3]) if len(sys.argv) > 3 else 25
 cfg = synth.CONFIGS["config2"]
 ctx = native.Context(0)
 ctx.tune(stream_pass=variant)
+if os.environ.get("ZOT_TUNE"):          # e.g. ZOT_TUNE=dedupe_variant=1
+    ctx.tune(**{k: int(v) for k, v in (kv.split("=") for kv in os.environ["ZOT_TUNE"].split(","))})
 d = ctx.synth_reads(synth.DEFAULT_SEED, 0, reads, cfg["L"], genome=cfg["genome"], sub_thr=synth.frac32(cfg["sub"]), n_thr=synth.frac32(cfg["n"]))
 cap = int(2 * (min(cfg["genome"], reads * cfg["L"]) + reads * cfg["L"] * cfg["sub"] * 22) * 1.25) + (1 << 20)
 outs = (ctx.empty(cap, np.uint64), ctx.empty(cap, np.uint32))

@@ -11,18 +11,24 @@
 //   * side lists of 128 entries a wave, drained 64 at a time as soon as 64 are there (full wavefronts, no worst-case tile to hold);
 // -- 11 K entries in 76 KB, and while one workgroup of the CU sorts and writes its block the other one inserts.
 #include "dedupe.hpp"
+#include <type_traits>
 
 namespace zk {
 
-template <int BLOCK_>
+// BATCH: the compare-and-swaps a thread has in flight at a time (their answers are looked at together); a wave's side list must
+// take what one batch can add at worst on top of the 63 entries a drain may leave.  ITEMS: tags a thread takes per tile; the next
+// tile is asked for before the current one is inserted, so a workgroup has 4 * TILE bytes on their way from memory.
+template <int BLOCK_, int BATCH_, int ITEMS_>
 struct Dedupe2Smem {
-    static constexpr int BLOCK = BLOCK_, ITEMS = 8, TILE = BLOCK * ITEMS, NW = BLOCK / 64, ALL = 11264, SPT = ALL / BLOCK, NB = 256, SIDE = 128;
-    static_assert(ALL % BLOCK == 0 && ALL % 8 == 0, "whole rounds, whole quads");
-    u32 keys[ALL];            // tags (after the count: the entries again, grouped by their top byte)
-    u32 cnt[ALL / 2];         // 16-bit counts: entry h in half (h & 1) of word h >> 1
-    u32 side[NW][SIDE];
-    u32 bc[NB];               // entries per top byte of the tag
-    u32 bbase[NB + 1];        // ... before it
+    static constexpr int BLOCK = BLOCK_, BATCH = BATCH_, ITEMS = ITEMS_, TILE = BLOCK * ITEMS, NW = BLOCK / 64, ALL = 11264, SPT = ALL / BLOCK,
+                         NB = 1024, SIDE = 64 + 64 * BATCH;
+    static_assert(ALL % BLOCK == 0 && ALL % 8 == 0 && ITEMS % BATCH == 0 && ITEMS % 4 == 0, "whole rounds, whole quads, whole batches");
+    alignas(16) u32 keys[ALL];            // tags (after the count: the entries again, grouped by their top ten bits)
+    alignas(16) u32 cnt[ALL / 2];         // 16-bit counts: entry h in half (h & 1) of word h >> 1
+    union {
+        u32 side[NW][SIDE];               // while the keys are inserted
+        struct { u32 bc[NB]; u32 bbase[NB + 1]; } g;          // afterwards: entries per group (the tag's top ten bits), and before it
+    };
     u32 ticket;
 };
 
@@ -31,74 +37,84 @@ struct Dedupe2Smem {
 template <int ITEMS>
 struct Dedupe2Next {
     u32 chunk;
-    u64 lo, hi;
+    u64 lo;          // where the block's keys start ...
+    u32 len;         // ... and how many they are (a block this kernel counts has fewer than 65 536)
     u32 tag[ITEMS];
 };
 
-template <int BLOCK, bool TAGIN, bool RDFIRST>
-__device__ __forceinline__ void dedupe2_block(const DedupeArgs& a, Dedupe2Smem<BLOCK>& sm, Dedupe2Next<8>& st, u32 (&ph)[8], u32& tlast) {
-    using S = Dedupe2Smem<BLOCK>;
-    constexpr int ITEMS = S::ITEMS, TILE = S::TILE, ALL = S::ALL, SPT = S::SPT, NB = S::NB;
-    constexpr u32 EMPTY = ~0u;            // no entry; the all-ones tag has the last entry to itself (see `home`)
-    constexpr u32 HS = ALL - 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const u32 chunk = st.chunk;
-    const u64 lo = st.lo, hi = st.hi;
-    const u32 maxc = (1u << a.pack) - 1u;
-    const u32 tmask = a.tag_bits >= 32 ? ~0u : (1u << a.tag_bits) - 1u;
-    // A whole tile: every thread takes ITEMS tags with 16-byte loads (TAGIN; a block starts wherever it starts: 4-byte aligned, no
-    // more) or ITEMS keys a stride apart.  The cut last tile: one element a stride apart each, the ones beyond the block not loaded.
-    // Which thread takes which key is the table's business alone.
-    auto load = [&](u64 base, u64 end, u32 (&t)[ITEMS]) {
-        if constexpr (TAGIN) {
-            if (base + TILE <= end) {
-                struct __attribute__((packed, aligned(4))) Tag4 { u32 a, b, c, d; };
-                static_assert(ITEMS % 4 == 0, "whole quads");
+// The tags [pos, pos + TILE) of the block that starts at `lo` (the same in every lane), as far as the block goes (rem = len - pos > 0).
+// A whole tile: every thread takes ITEMS tags with 16-byte loads (TAGIN; a block starts wherever it starts: 4-byte aligned, no more) or
+// ITEMS keys a stride apart.  The cut last tile: element i * BLOCK + tid each, the ones beyond the block not loaded.  Which thread
+// takes which key is the table's business alone.
+template <int BLOCK, int ITEMS, bool TAGIN>
+__device__ __forceinline__ void dedupe2_load(const DedupeArgs& a, u64 lo, u32 pos, u32 rem, u32 tmask, u32 (&t)[ITEMS]) {
+    constexpr u32 TILE = BLOCK * ITEMS;
+    u32 tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));          // (opaque: or every index derived from it is computed once, as a 64-bit pair, and kept for the whole kernel)
+    if constexpr (TAGIN) {
+        const u32* tp = a.tin + lo + pos;
+        if (rem >= TILE) {
+            struct __attribute__((packed, aligned(4))) Tag4 { u32 a, b, c, d; };
+            static_assert(ITEMS % 4 == 0, "whole quads");
 #pragma unroll
-                for (int i = 0; i < ITEMS / 4; i++) {
-                    const Tag4 q = *reinterpret_cast<const Tag4*>(a.tin + base + (u64)i * (4 * BLOCK) + 4 * tid);
-                    t[4 * i] = q.a; t[4 * i + 1] = q.b; t[4 * i + 2] = q.c; t[4 * i + 3] = q.d;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < ITEMS; i++) {
-                    const u64 g = base + (u64)i * BLOCK + tid;
-                    t[i] = g < end ? a.tin[g] : 0u;
-                }
+            for (int i = 0; i < ITEMS / 4; i++) {
+                const Tag4 q = *reinterpret_cast<const Tag4*>(tp + (u32)i * (4 * BLOCK) + 4 * tid);
+                t[4 * i] = q.a; t[4 * i + 1] = q.b; t[4 * i + 2] = q.c; t[4 * i + 3] = q.d;
             }
-        } else if (base + TILE <= end) {
-            const u64* p = a.kin + base + tid;
-#pragma unroll
-            for (int i = 0; i < ITEMS; i++) t[i] = (u32)p[i * BLOCK] & tmask;
         } else {
 #pragma unroll
             for (int i = 0; i < ITEMS; i++) {
-                const u64 g = base + (u64)i * BLOCK + tid;
-                t[i] = g < end ? (u32)a.kin[g] & tmask : 0u;
+                const u32 g = (u32)i * BLOCK + tid;
+                t[i] = g < rem ? tp[g] : 0u;
             }
         }
-    };
-    auto next_block = [&]() {          // call after a barrier that follows the ticket's store
-        st.chunk = (u32)__builtin_amdgcn_readfirstlane((int)sm.ticket);
-        st.lo = st.hi = 0;
-        if (st.chunk < a.chunks) { st.lo = a.cuts[st.chunk]; st.hi = a.cuts[st.chunk + 1]; }
-        if (st.hi > st.lo && st.hi - st.lo < (u64)a.limit) load(st.lo, st.hi, st.tag);
+    } else {
+        const u64* kp = a.kin + lo + pos;
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const u32 g = (u32)i * BLOCK + tid;
+            t[i] = g < rem ? (u32)kp[g] & tmask : 0u;
+        }
+    }
+}
+
+template <int BLOCK, int BATCH, int ITEMS_, bool TAGIN>
+__device__ __forceinline__ void dedupe2_block(const DedupeArgs& a, Dedupe2Smem<BLOCK, BATCH, ITEMS_>& sm, Dedupe2Next<ITEMS_>& st, u32 (&ph)[8], u32& tlast) {
+    using S = Dedupe2Smem<BLOCK, BATCH, ITEMS_>;
+    constexpr int ITEMS = S::ITEMS, TILE = S::TILE, ALL = S::ALL, SPT = S::SPT, NB = S::NB;
+    constexpr u32 EMPTY = ~0u;            // no entry; the all-ones tag has the last entry to itself (see `home`)
+    constexpr u32 HS = ALL - 1;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));          // (opaque per block: nothing derived from it is kept from one block to the next)
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 chunk = st.chunk;
+    const u64 lo = st.lo;
+    const u32 len = st.len;
+    const u32 maxc = (1u << a.pack) - 1u;
+    const u32 tmask = a.tag_bits >= 32 ? ~0u : (1u << a.tag_bits) - 1u;
+    auto next_block = [&](u32 t) {          // t: the ticket drawn at this block's start (read after a barrier)
+        st.chunk = t; st.lo = 0; st.len = 0;
+        if (t < a.chunks) {
+            const u64 nlo = a.cuts[t], nhi = a.cuts[t + 1];
+            st.lo = nlo;
+            st.len = nhi - nlo < (u64)a.limit ? (u32)(nhi - nlo) : ~0u;          // ~0: too large for this kernel, nothing is loaded
+        }
+        if (st.len - 1u < ~0u - 1u) dedupe2_load<BLOCK, ITEMS, TAGIN>(a, st.lo, 0, st.len, tmask, st.tag);
     };
     if (tid == 0) sm.ticket = atomicAdd(a.counter, 1u);          // the block after this one: read after the next barrier
-    if (hi <= lo || hi - lo >= (u64)a.limit) {
+    if (len == 0 || len == ~0u) {
         // nothing to count -- or more keys than a 16-bit count is safe for: dedupe_kernel's business
         if (tid == 0) {
-            if (hi > lo) a.retry[atomicAdd(a.n_retry, 1u)] = chunk;
+            if (len) a.retry[atomicAdd(a.n_retry, 1u)] = chunk;
             a.nwords[chunk] = 0;
         }
         if (a.sub && tid < 64) a.sub[(u64)chunk * 64 + tid] = 0;
         __syncthreads();
-        next_block();
+        next_block((u32)__builtin_amdgcn_readfirstlane((int)sm.ticket));
         return;
     }
     for (int q = tid; q < ALL / 4; q += BLOCK) reinterpret_cast<uint4*>(sm.keys)[q] = make_uint4(~0u, ~0u, ~0u, ~0u);
     for (int q = tid; q < ALL / 8; q += BLOCK) reinterpret_cast<uint4*>(sm.cnt)[q] = make_uint4(0, 0, 0, 0);
-    if (tid < NB) sm.bc[tid] = 0;
     __syncthreads();
     DD_PHASE(0);          // table cleared
     const u32 nchunk = (u32)__builtin_amdgcn_readfirstlane((int)sm.ticket);
@@ -107,8 +123,9 @@ __device__ __forceinline__ void dedupe2_block(const DedupeArgs& a, Dedupe2Smem<B
     auto home = [&](u32 e) -> u32 {
         // the all-ones tag (= the empty marker) has the last entry to itself: there the swap of "empty" for "empty" succeeds and
         // leaves the word as it is; no other key is ever sent there
-        const u32 x = e * 0x9E3779B1u;
-        return e == EMPTY ? HS : (u32)(((u64)x * HS) >> 32);
+        u32 hh = __umulhi(e * 0x9E3779B1u, HS);
+        asm("" : "+v"(hh));          // (opaque: left to itself the compiler branches around the two multiplies for the one tag that does not need them)
+        return e == EMPTY ? HS : hh;
     };
     auto count = [&](u32 h, u32 inc) { atomicAdd(&sm.cnt[h >> 1], inc << ((h & 1u) << 4)); };
     // up to 64 entries of the wave's side list into the table by linear probing
@@ -126,46 +143,46 @@ __device__ __forceinline__ void dedupe2_block(const DedupeArgs& a, Dedupe2Smem<B
             if (p < ALL) count(h, 1u); else bad = 1;
         }
     };
-    // The common case has no loop and no branch: one compare-and-swap at the tag's home entry (RDFIRST: a plain read, the swap only
-    // for the lanes that see "empty"), the count added as 1 or 0 (adding 0 to another key's entry harms nobody); a key that finds
-    // another key at home goes to the wave's side list (its place from a ballot, no atomic).
-    auto insert = [&](u32 e, bool valid) {
-        const u32 h = home(e);
-        u32 old;
-        if constexpr (RDFIRST) {
-            old = sm.keys[h];
-            if (old == EMPTY && valid) old = atomicCAS(&sm.keys[h], EMPTY, e);
-            if (!valid) old = e;
-        } else old = valid ? atomicCAS(&sm.keys[h], EMPTY, e) : e;
-        const bool ok = old == EMPTY || old == e;
-        count(h, (ok && valid) ? 1u : 0u);
-        const u64 m = __ballot(!ok);
-        if (m) {
-            if (!ok) sm.side[wave][nside + popc_below(m)] = e;
+    // The common case has no loop and no branch: one compare-and-swap at the tag's home entry, the count added as 1 or 0 (adding 0
+    // to another key's entry harms nobody); a key that finds another key at home goes to the wave's side list (its place from a
+    // ballot, no atomic).  BATCH swaps are issued before the first answer is looked at.  (A plain read first and the swap only for
+    // the lanes that see "empty": 13.5 against 13.3 ms.)
+    auto insert = [&](auto whole, const u32 (&e)[BATCH], const bool (&valid)[BATCH]) {          // whole: every key of the batch is one (a whole tile)
+        constexpr bool WHOLE = decltype(whole)::value;
+        u32 h[BATCH], old[BATCH];
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) h[j] = home(e[j]);
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) old[j] = (WHOLE || valid[j]) ? atomicCAS(&sm.keys[h[j]], EMPTY, e[j]) : e[j];
+#pragma unroll
+        for (int j = 0; j < BATCH; j++) {
+            const bool ok = old[j] == EMPTY || old[j] == e[j];
+            count(h[j], (ok && (WHOLE || valid[j])) ? 1u : 0u);
+            const u64 m = __ballot(!ok);
+            if (!ok) sm.side[wave][nside + popc_below(m)] = e[j];
             nside += (u32)__popcll(m);
-            if (nside >= 64) { nside -= 64; drain(nside, 64); }
         }
+        while (nside >= 64) { nside -= 64; drain(nside, 64); }
     };
     u32 tag[ITEMS], nt[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) tag[i] = st.tag[i];          // the first tile was asked for during the previous block
-    for (u64 base = lo; base < hi; base += TILE) {
-        if (base + TILE < hi) load(base + TILE, hi, nt);
-        if (base + TILE <= hi) {
+    for (u32 pos = 0; pos < len; pos += TILE) {
+        const u32 rem = len - pos;
+        if (rem > (u32)TILE) dedupe2_load<BLOCK, ITEMS, TAGIN>(a, lo, pos + TILE, rem - TILE, tmask, nt);
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++) insert(tag[i], true);
-        } else {
+        for (int i0 = 0; i0 < ITEMS; i0 += BATCH) {
+            u32 e[BATCH];
+            bool valid[BATCH];
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++) insert(tag[i], base + (u64)i * BLOCK + tid < hi);
+            for (int j = 0; j < BATCH; j++) { e[j] = tag[i0 + j]; valid[j] = (u32)(i0 + j) * BLOCK + tid < rem; }
+            if (rem >= (u32)TILE) insert(std::true_type(), e, valid); else insert(std::false_type(), e, valid);
         }
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) tag[i] = nt[i];
     }
     drain(0, nside);
     DD_PHASE(1);          // keys inserted
-    st.chunk = nchunk; st.lo = st.hi = 0;
-    if (nchunk < a.chunks) { st.lo = a.cuts[nchunk]; st.hi = a.cuts[nchunk + 1]; }
-    if (st.hi > st.lo && st.hi - st.lo < (u64)a.limit) load(st.lo, st.hi, st.tag);          // the next block's first tile travels while this one is sorted and written
     const int any_bad = __syncthreads_or((int)bad);
     DD_PHASE(2);          // ... every wave done
     if (any_bad) {
@@ -175,56 +192,72 @@ __device__ __forceinline__ void dedupe2_block(const DedupeArgs& a, Dedupe2Smem<B
             a.nwords[chunk] = 0;
         }
         if (a.sub && tid < 64) a.sub[(u64)chunk * 64 + tid] = 0;
+        next_block(nchunk);
         return;
     }
-    // ---- the block's entries, sorted: a counting sort on the tag's top byte, then ranks inside each byte's group ---------
-    // thread t takes the entries t, t + BLOCK, ... into registers with their places in their byte groups (a returning add); the
-    // table's memory then takes them back grouped
+    // ---- the block's entries, sorted: a counting sort on the tag's top ten bits, then ranks inside each group of ~3 -----------
+    // thread t takes the entries t, t + BLOCK, ... into registers with their places in their groups (a returning add); the table's
+    // memory then takes them back grouped.  (256 groups of a dozen entries: the rank loop runs as long as the largest group of a
+    // wavefront, one LDS round trip per turn -- 16 K of a block's 58 K cycles.)
+    sm.g.bc[tid] = 0; sm.g.bc[tid + BLOCK] = 0;          // the side lists are done with: every wave has passed the barrier above
+    static_assert(NB == 2 * BLOCK, "two counters a thread");
     u32 et[SPT], ec[SPT];          // ec: count | place in the group << 16
-    const int bsh = a.tag_bits > 8 ? a.tag_bits - 8 : 0;
+    const int gb = a.tag_bits < 10 ? a.tag_bits : 10, bsh = a.tag_bits - gb;
     const u16* cnt16 = reinterpret_cast<const u16*>(sm.cnt);
 #pragma unroll
     for (int j = 0; j < SPT; j++) {
         et[j] = sm.keys[tid + j * BLOCK];
         ec[j] = cnt16[tid + j * BLOCK];
     }
-#pragma unroll
-    for (int j = 0; j < SPT; j++)
-        if (ec[j]) ec[j] |= atomicAdd(&sm.bc[(et[j] >> bsh) & (NB - 1)], 1u) << 16;
     __syncthreads();
-    DD_PHASE(3);          // entries read, byte groups counted
-    if (wave == 0) {
-        u32 c4[4], sum = 0;
 #pragma unroll
-        for (int r = 0; r < 4; r++) { c4[r] = sm.bc[4 * lane + r]; sum += c4[r]; }
+    for (int j = 0; j < SPT; j++) {
+        if (ec[j]) ec[j] |= atomicAdd(&sm.g.bc[(et[j] >> bsh) & (NB - 1)], 1u) << 16;
+        if (j % 6 == 5) __builtin_amdgcn_sched_barrier(0);          // (all SPT adds scheduled at once: their addresses and answers spill)
+    }
+    __syncthreads();
+    DD_PHASE(3);          // entries read, groups counted
+    if (wave == 0) {
+        constexpr int PER = NB / 64;
+        u32 cs[PER], sum = 0;
+#pragma unroll
+        for (int r = 0; r < PER; r++) { cs[r] = sm.g.bc[PER * lane + r]; sum += cs[r]; }
         const u32 inc = wave_incl_scan_u32(sum);
         u32 run = inc - sum;
 #pragma unroll
-        for (int r = 0; r < 4; r++) { sm.bbase[4 * lane + r] = run; run += c4[r]; }
-        if (lane == 63) sm.bbase[NB] = inc;
+        for (int r = 0; r < PER; r++) { sm.g.bbase[PER * lane + r] = run; run += cs[r]; }
+        if (lane == 63) sm.g.bbase[NB] = inc;
     }
     __syncthreads();
-    const u32 total = sm.bbase[NB];
+    const u32 total = sm.g.bbase[NB];
     if (tid == 0) a.nwords[chunk] = total;
-    if (a.sub && tid < 64) a.sub[(u64)chunk * 64 + tid] = sm.bbase[4 * tid + 4] - sm.bbase[4 * tid];          // four top bytes = one 6-bit start
+    if (a.sub && tid < 64) a.sub[(u64)chunk * 64 + tid] = sm.g.bbase[16 * tid + 16] - sm.g.bbase[16 * tid];          // sixteen groups = one 6-bit start (tag_bits >= 14)
     u16* cw16 = reinterpret_cast<u16*>(sm.cnt);
 #pragma unroll
     for (int j = 0; j < SPT; j++) {
         if (ec[j]) {
-            const u32 p = sm.bbase[(et[j] >> bsh) & (NB - 1)] + (ec[j] >> 16);
+            const u32 p = sm.g.bbase[(et[j] >> bsh) & (NB - 1)] + (ec[j] >> 16);
             sm.keys[p] = et[j];
             cw16[p] = (u16)ec[j];
         }
     }
     __syncthreads();
-    DD_PHASE(4);          // grouped by top byte
+    DD_PHASE(4);          // grouped
+    next_block(nchunk);          // the next block's first tile travels while this one is ranked and written (asked for any earlier, its
+                                 // registers are held beside the entries above: 20 spilled)
     const u64 hi_part = (u64)chunk << a.tag_bits;          // the bits every key of the block has above its tag
     for (u32 i = (u32)tid; i < total; i += BLOCK) {
         const u32 mine = sm.keys[i];
         const u32 b = (mine >> bsh) & (NB - 1);
-        const u32 g0 = sm.bbase[b], g1 = sm.bbase[b + 1];
+        const u32 g0 = sm.g.bbase[b], g1 = sm.g.bbase[b + 1];
         u32 rank = 0;
-        for (u32 q = g0; q < g1; q++) rank += sm.keys[q] < mine ? 1u : 0u;
+        for (u32 q = g0; q < g1; q += 4) {          // four of the group at a time: one round trip for most groups
+            u32 o[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[r] = sm.keys[q + r < (u32)ALL ? q + r : (u32)ALL - 1];
+#pragma unroll
+            for (int r = 0; r < 4; r++) rank += (q + r < g1 && o[r] < mine) ? 1u : 0u;
+        }
         const u32 c = cnt16[i];
         const u64 k = hi_part | (u64)mine;
         if (c > maxc) {
@@ -239,31 +272,30 @@ __device__ __forceinline__ void dedupe2_block(const DedupeArgs& a, Dedupe2Smem<B
 
 // Persistent: two workgroups per CU draw the blocks from a counter -- in order, not strided: the sizes go with the first bases, a
 // stride of the grid would give one workgroup all the big ones.
-template <int BLOCK, bool TAGIN, bool RDFIRST>
+template <int BLOCK, int BATCH, int ITEMS, bool TAGIN>
 __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void dedupe2_kernel(DedupeArgs a) {
-    using S = Dedupe2Smem<BLOCK>;
+    using S = Dedupe2Smem<BLOCK, BATCH, ITEMS>;
     __shared__ S sm;
     static_assert(sizeof(S) <= 80 * 1024, "two workgroups per CU");
-    Dedupe2Next<S::ITEMS> st;
+    Dedupe2Next<ITEMS> st;
     if (threadIdx.x == 0) sm.ticket = atomicAdd(a.counter, 1u);
     __syncthreads();
     st.chunk = (u32)__builtin_amdgcn_readfirstlane((int)sm.ticket);
-    st.lo = st.hi = 0;
-    if (st.chunk < a.chunks) { st.lo = a.cuts[st.chunk]; st.hi = a.cuts[st.chunk + 1]; }
+    st.lo = 0; st.len = 0;
     const u32 tmask = a.tag_bits >= 32 ? ~0u : (1u << a.tag_bits) - 1u;
-#pragma unroll
-    for (int i = 0; i < S::ITEMS; i++) {
-        const u64 g = st.lo + (u64)i * BLOCK + threadIdx.x;
-        if constexpr (TAGIN) st.tag[i] = g < st.hi ? a.tin[g] : 0u;
-        else st.tag[i] = g < st.hi ? (u32)a.kin[g] & tmask : 0u;
+    if (st.chunk < a.chunks) {
+        const u64 nlo = a.cuts[st.chunk], nhi = a.cuts[st.chunk + 1];
+        st.lo = nlo;
+        st.len = nhi - nlo < (u64)a.limit ? (u32)(nhi - nlo) : ~0u;
     }
+    if (st.len - 1u < ~0u - 1u) dedupe2_load<BLOCK, ITEMS, TAGIN>(a, st.lo, 0, st.len, tmask, st.tag);
     __syncthreads();          // the ticket word is free again
     u32 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     u32 tlast = a.dbg ? (u32)__builtin_amdgcn_s_memtime() : 0u;
     (void)tlast;
     u32 nblk = 0;
     while (st.chunk < a.chunks) {
-        dedupe2_block<BLOCK, TAGIN, RDFIRST>(a, sm, st, ph, tlast);          // leaves the next block in st
+        dedupe2_block<BLOCK, BATCH, ITEMS, TAGIN>(a, sm, st, ph, tlast);          // leaves the next block in st
         __syncthreads();          // the table and the ticket word are free again
         DD_PHASE(6);
         nblk++;
@@ -274,18 +306,16 @@ __global__ __launch_bounds__(BLOCK, 2 * BLOCK / 256) void dedupe2_kernel(DedupeA
     }
 }
 
-// variant: bit 1 = a plain read before the compare-and-swap.  (1024-thread workgroups, two to a CU, have 64 registers a thread: the
-// entries a thread holds while the block is sorted do not fit -- 25 to 40 spilled; not instantiated.)
+// variant: bits 0-1 = compare-and-swaps in flight per thread (0: 4, 1: 1, 2: 2).  Tiles of 8 tags a thread; 16 (twice the bytes on
+// their way from memory): 14.5 against 12.6 ms.  (1024-thread workgroups, two to a CU, have 64 registers a thread: the entries a
+// thread holds while the block is sorted do not fit -- 25 to 40 spilled; not instantiated.)
 int launch_dedupe2(zk_ctx* c, const DedupeArgs& a, bool tagin, int variant) {
     const u32 want = 2u * (u32)c->num_cus;
     const u32 grid = a.chunks < want ? a.chunks : want;
-#define ZK_DD2(B, T, R) hipLaunchKernelGGL((dedupe2_kernel<B, T, R>), dim3(grid), dim3(B), 0, c->stream, a)
-    switch ((variant & 2) | (tagin ? 4 : 0)) {
-        case 0: ZK_DD2(512, false, false); break;
-        case 2: ZK_DD2(512, false, true); break;
-        case 4: ZK_DD2(512, true, false); break;
-        default: ZK_DD2(512, true, true); break;
-    }
+#define ZK_DD2(N, T) hipLaunchKernelGGL((dedupe2_kernel<512, N, 8, T>), dim3(grid), dim3(512), 0, c->stream, a)
+#define ZK_DD2B(T) switch (variant & 3) { case 1: ZK_DD2(1, T); break; case 2: ZK_DD2(2, T); break; default: ZK_DD2(4, T); break; }
+    if (tagin) ZK_DD2B(true) else ZK_DD2B(false)
+#undef ZK_DD2B
 #undef ZK_DD2
     ZK_HIP(c, hipGetLastError());
     return ZK_OK;
