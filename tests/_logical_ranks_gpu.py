@@ -5,7 +5,8 @@ merged over 8 LOGICAL ranks -- eight threads, each with its own zk_ctx on the sa
 zotmer_amd/parallel.py (Exchange.merge_sets / dist_pair / gather_to_root with GpuOps, i.e. zk_merge_n, zk_lower_bound,
 zk_hash_partition, zk_project_dedupe, zk_split on the device).  Only the transport is a stand-in: `ThreadComm` moves the
 pieces with device-to-device copies and reduces integers under a barrier, where the real thing calls RCCL.  Compared
-bit for bit with one oracle merge of all 64 sets, for both owner functions; dist at K = 25 and projected to K = 12.
+bit for bit with one oracle merge of all 64 sets, for both owner functions; dist at K = 25 and projected to K = 12; the kmerize
+exchange (canonical lists cut by owner, exchanged, strands rebuilt by the owner) at K = 25 and at K = 31.
 """
 import os
 import sys
@@ -22,6 +23,7 @@ from zotmer_amd import native, parallel, synth    # noqa: E402
 W = 8
 SCALE = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0004        # 64 sets x 20 000 keys from a pool of 80 000
 K = 25
+K31 = 31
 
 
 class ThreadComm:
@@ -130,6 +132,17 @@ def worker(rank, owner, host_sets, results):
         gk, gc = exk.gather_to_root(bk, bc)
         if rank == 0:
             out["kz_k"], out["kz_c"] = gk.to_host(), gc.to_host()
+        # the same at K = 31 (BASELINE config 5: 62-bit keys -- the balanced cuts' 16 + 16-bit histograms sit at the top of a key
+        # twelve bits wider, the owner of a k-mer is the owner of its canonical form)
+        ck, cc, st = ctx.kmerize(d, K31, native.KMERIZE_CANONICAL_ONLY)
+        exk = parallel.Exchange(ctx, None, K31, owner=owner, seed=11, comm=comm)
+        kt, ct, n = exk.ops.to_tensors(ck, cc)
+        bk, bc = exk.kmerize_finish(kt, ct, n)
+        assert exk.verify_global(bk, bc, ctx.stream_checksum(d, K31)), "kmerize K = 31: checksum of checksums"
+        out["kz31_owned"] = bk.n
+        gk, gc = exk.gather_to_root(bk, bc)
+        if rank == 0:
+            out["kz31_k"], out["kz31_c"] = gk.to_host(), gc.to_host()
         results[rank] = out
         ctx.close()
     except BaseException as e:          # noqa: BLE001
@@ -181,7 +194,11 @@ def main():
         assert np.array_equal(r0["kz_k"], wantk["kmers"]) and np.array_equal(r0["kz_c"], wantk["counts"]), owner + ": kmerize over 8 ranks"
         ksz = [r["kz_owned"] for r in results]
         assert sum(ksz) == len(wantk["kmers"]) and max(ksz) <= 1.25 * len(wantk["kmers"]) / W, (owner, ksz)
-        print("LOGICAL-RANKS-OK", owner, len(zs), sizes, ksz)
+        want31 = zo.kmerize(K31, reads)
+        assert np.array_equal(r0["kz31_k"], want31["kmers"]) and np.array_equal(r0["kz31_c"], want31["counts"]), owner + ": kmerize K = 31 over 8 ranks"
+        ksz31 = [r["kz31_owned"] for r in results]
+        assert sum(ksz31) == len(want31["kmers"]) and max(ksz31) <= 1.25 * len(want31["kmers"]) / W, (owner, ksz31)
+        print("LOGICAL-RANKS-OK", owner, len(zs), sizes, ksz, ksz31)
 
 
 if __name__ == "__main__":

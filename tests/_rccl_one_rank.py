@@ -1,6 +1,12 @@
 """Run by tests/test_gpu_multigpu.py in its own process: the two RCCL transports with ONE rank on the GPU box (the box has one
 GPU; the 8-GPU run is the driver's).  What one rank can prove on hardware:
-  * zk_comm_* loads RCCL, creates a communicator, all-reduces and runs the all-to-all-v entry (self piece) -- NativeComm;
+  * zk_comm_* loads RCCL and creates a communicator.  With one rank zk_all_to_all_v is a device copy of the kept piece and
+    zk_allreduce_u64 returns its input -- no RCCL call is made (`native_verified`, `native_allreduce`: the plumbing, no more);
+  * the RCCL calls themselves, with ZK_TUNE_COMM_SELF_LOOP: the kept piece goes through grouped ncclSend / ncclRecv to the rank
+    itself, in rounds of a forced small size (many rounds, a ragged last one, offsets that are not zero, empty pieces, 4- and
+    8-byte elements), compared byte for byte with a plain device copy; zk_allreduce_u64 through ncclAllReduce (sum and max);
+    and the product path -- Exchange.exchange_and_merge over that transport -- checked by the order-free checksums
+    (`selfloop_*`).  What it cannot prove: the (me +- d) % W pairing and the offsets of OTHER ranks' pieces (world > 1);
   * torch.distributed "nccl": Exchange.exchange_and_merge with the round size forced small (many staged rounds), checked by
     the order-free checksums (zk_checksum of the merged table == zk_stream_checksum of the reads), as bench.py does;
   * the round-1 finding "one all_to_all_single above 1 GiB per peer arrives corrupt": a bare contiguous int64 tensor of
@@ -52,6 +58,38 @@ out["native_verified"] = bool(exn.verify_global(mk2, mc2, want)) and mk2.n == k.
 out["native_allreduce"] = comm.all_reduce([5, (1 << 64) - 1]) == [5, (1 << 64) - 1]
 comm.close()
 
+# --- the RCCL calls of comm.hip with the one rank there is: ncclSend / ncclRecv to self in rounds, ncclAllReduce
+comm = parallel.NativeComm(ctx, dist, self_loop=True)
+cases, bad_cases = 0, []
+for eb, tdt in ((8, torch.int64), (4, torch.int32)):
+    for n in (0, 1, 12345, (1 << 20) + 7):
+        for chunk in (40_000, 1_000_003, 0):          # bytes per round: many rounds + a ragged tail; not a multiple of the element; the default
+            ctx.tune(comm_chunk=chunk)
+            soff, roff = 3, 5
+            src_t = (torch.arange(n + soff + 2, dtype=torch.int64, device="cuda") * 2654435761 + 12345).to(tdt)
+            dst_t = torch.full((n + roff + 2,), -7, dtype=tdt, device="cuda")
+            ctx.all_to_all_v(src_t.data_ptr(), [soff], [n], dst_t.data_ptr(), [roff], [n], eb)
+            ctx.sync()
+            ok = bool(torch.equal(dst_t[roff:roff + n], src_t[soff:soff + n])) and bool((dst_t[:roff] == -7).all()) and bool((dst_t[roff + n:] == -7).all())
+            cases += 1
+            if not ok:
+                bad_cases.append((eb, n, chunk))
+out["selfloop_send_recv_cases"] = cases
+out["selfloop_send_recv_bad"] = bad_cases
+out["selfloop_rounds_max"] = -(-(8 * ((1 << 20) + 7)) // 40_000)
+out["selfloop_allreduce"] = (comm.all_reduce([5, (1 << 64) - 1, 0]) == [5, (1 << 64) - 1, 0]
+                             and comm.all_reduce([7, 1 << 63], "max") == [7, 1 << 63]
+                             and list(comm.all_reduce(np.arange(1000, dtype=np.uint64))) == list(range(1000)))
+ctx.tune(comm_chunk=300_000)
+for owner in ("range", "hash"):
+    exs = parallel.Exchange(ctx, dist, K, comm=comm, owner=owner, seed=5)
+    if owner == "range":
+        exs.balanced_cuts([(kt, k.n)])
+    mk3, mc3 = exs.exchange_and_merge(kt, ct, k.n)
+    out["selfloop_exchange_%s_verified" % owner] = bool(exs.verify_global(mk3, mc3, want)) and mk3.n == k.n
+ctx.tune(comm_chunk=0)
+comm.close()
+
 # --- > 1 GiB per peer: bare all_to_all_single vs the chunked path, against a device copy
 n_big = (1 << 27) + (1 << 20)
 src = torch.arange(n_big, dtype=torch.int64, device="cuda") * 2654435761
@@ -71,5 +109,7 @@ out["torch"] = torch.__version__
 dist.destroy_process_group()
 ctx.close()
 print("RCCL-ONE-RANK " + json.dumps(out))
-ok = out["torch_chunked_verified"] and out["native_verified"] and out["native_allreduce"] and out["chunked_gt_1GiB_intact"]
+ok = (out["torch_chunked_verified"] and out["native_verified"] and out["native_allreduce"] and out["chunked_gt_1GiB_intact"]
+      and not out["selfloop_send_recv_bad"] and out["selfloop_allreduce"] and out["selfloop_exchange_range_verified"]
+      and out["selfloop_exchange_hash_verified"])
 sys.exit(0 if ok else 1)

@@ -150,6 +150,9 @@ def test_rccl_transports_with_one_rank():
             json.dump(rec, f, indent=1)
     assert r.returncode == 0, (rec, r.stderr[-3000:])
     assert rec["torch_chunked_verified"] and rec["native_verified"] and rec["native_allreduce"] and rec["chunked_gt_1GiB_intact"]
+    # the RCCL calls themselves (ncclSend / ncclRecv to self in rounds, ncclAllReduce), not only the plumbing around them
+    assert rec["selfloop_send_recv_cases"] == 24 and not rec["selfloop_send_recv_bad"] and rec["selfloop_allreduce"]
+    assert rec["selfloop_exchange_range_verified"] and rec["selfloop_exchange_hash_verified"]
 
 
 def test_commands_distributed_code_path_with_one_rank(tmp_path):

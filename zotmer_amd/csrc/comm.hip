@@ -118,21 +118,24 @@ int zk_all_to_all_v(zk_ctx* c, const void* d_send, const uint64_t* send_off, con
     const int W = c->comm_world, me = c->comm_rank;
     const uint64_t eb = (uint64_t)elem_bytes;
     if (send_cnt[me] != recv_cnt[me]) return fail(c, ZK_EINVAL, "zk_all_to_all_v: the piece kept locally has two sizes");
-    if (send_cnt[me])
+    // The piece a rank keeps is a device copy -- unless ZK_TUNE_COMM_SELF_LOOP sends it through RCCL as well (a grouped ncclSend /
+    // ncclRecv to the rank itself, in the same rounds as every other piece): that is how the loop below runs on a box with one GPU.
+    const bool self_loop = c->comm_self_loop != 0;
+    if (send_cnt[me] && !self_loop)
         ZK_HIP(c, hipMemcpyAsync((char*)d_recv + recv_off[me] * eb, (const char*)d_send + send_off[me] * eb, send_cnt[me] * eb,
                                  hipMemcpyDeviceToDevice, c->stream));
-    if (W == 1) return ZK_OK;
+    if (W == 1 && !self_loop) return ZK_OK;
     const uint64_t chunk = c->comm_chunk_bytes ? c->comm_chunk_bytes : (256ull << 20);     // bytes per message and round
     uint64_t biggest = 0;
     for (int p = 0; p < W; p++) {
-        if (p == me) continue;
+        if (p == me && !self_loop) continue;
         if (send_cnt[p] * eb > biggest) biggest = send_cnt[p] * eb;
         if (recv_cnt[p] * eb > biggest) biggest = recv_cnt[p] * eb;
     }
     const uint64_t rounds = div_up(biggest, chunk);
     for (uint64_t j = 0; j < rounds; j++) {
         ZK_NCCL(c, r->GroupStart());
-        for (int d = 1; d < W; d++) {
+        for (int d = self_loop ? 0 : 1; d < W; d++) {
             // talk to (me + d) and (me - d) in the same step, so that every link is busy in both directions
             const int to = (me + d) % W, from = (me - d + W) % W;
             const uint64_t sb = send_cnt[to] * eb, rb = recv_cnt[from] * eb;
@@ -156,7 +159,7 @@ int zk_allreduce_u64(zk_ctx* c, uint64_t* vals, uint64_t n, int op) {
     if (!c->comm) return fail(c, ZK_EINVAL, "zk_allreduce_u64: no communicator (call zk_comm_init)");
     if (n == 0) return ZK_OK;
     if (!vals || (op != ZK_REDUCE_SUM && op != ZK_REDUCE_MAX)) return fail(c, ZK_EINVAL, "zk_allreduce_u64: bad argument");
-    if (c->comm_world == 1) return ZK_OK;
+    if (c->comm_world == 1 && !c->comm_self_loop) return ZK_OK;          // (ZK_TUNE_COMM_SELF_LOOP: through ncclAllReduce with one rank as well)
     arena_reset(c);
     u64* d;
     ZK_TRY(arena_alloc(c, 8 * n, (void**)&d));

@@ -68,6 +68,8 @@ struct zk_ctx {
     void* comm = nullptr;
     int comm_world = 1, comm_rank = 0;
     uint64_t comm_chunk_bytes = 0;      // bytes per message and round of zk_all_to_all_v (0 = 256 MiB; zk_tune, tests)
+    int comm_self_loop = 0;             // tests: the piece a rank keeps travels through ncclSend / ncclRecv to itself as well, and one rank
+                                        // all-reduces through ncclAllReduce (the RCCL calls of comm.hip on a box with one GPU)
 
     void* ring = nullptr;               // page-locked staging ring + copy stream of the file <-> device paths (ingest.hip)
 

@@ -167,9 +167,13 @@ class NativeComm:
 
     name = "zk_comm (RCCL send/recv)"
 
-    def __init__(self, ctx, dist=None, world=None, rank=None, uid=None):
+    def __init__(self, ctx, dist=None, world=None, rank=None, uid=None, self_loop=False):
         from zotmer_amd import native
         self.ctx = ctx
+        # self_loop (tests on a box with one GPU): the piece a rank keeps goes through ncclSend / ncclRecv too, and a single
+        # rank still calls ncclAllReduce -- zk_tune(ZK_TUNE_COMM_SELF_LOOP)
+        self.self_loop = bool(self_loop)
+        ctx.tune(comm_self_loop=int(self.self_loop))
         if dist is not None:
             world, rank = dist.get_world_size(), dist.get_rank()
             box = [native.Context.comm_unique_id() if rank == 0 else None]
@@ -185,11 +189,13 @@ class NativeComm:
 
     def close(self):
         self.ctx.comm_destroy()
+        if self.self_loop:
+            self.ctx.tune(comm_self_loop=0)
 
     def all_reduce(self, vals, op="sum"):
         as_array = isinstance(vals, np.ndarray)
         a = np.ascontiguousarray(vals, dtype=np.uint64) if as_array else np.array([int(v) & M64 for v in vals], dtype=np.uint64)
-        if self.world > 1 and a.size:
+        if (self.world > 1 or self.self_loop) and a.size:
             a = self.ctx.allreduce_u64(a, 0 if op == "sum" else 1)
         return a if as_array else [int(v) for v in a]
 
