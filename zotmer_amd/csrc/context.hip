@@ -85,6 +85,13 @@ void prof_end(zk_ctx* c) {
     if (!c->profile || c->prof.empty()) return;
     (void)hipEventRecord(c->prof.back().b, c->stream);
 }
+// the bytes a launch wrote, when only its result says how many (distinct keys of a dedupe, entries of a union): added to the
+// record of that tag opened last
+void prof_add_bytes(zk_ctx* c, int tag, uint64_t bytes) {
+    if (!c->profile) return;
+    for (size_t i = c->prof.size(); i-- > 0;)
+        if (c->prof[i].tag == tag) { c->prof[i].bytes += bytes; return; }
+}
 
 int lookback_begin(zk_ctx* c, uint64_t words, uint32_t tiles, u32* epoch, u32* ticket_base) {
     if (words > c->status_words) {

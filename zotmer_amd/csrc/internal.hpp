@@ -115,6 +115,7 @@ int check_device_error(zk_ctx* c);
 // per-launch timing: bracket a launch with prof_begin / prof_end (no-ops unless enabled)
 void prof_begin(zk_ctx* c, int tag, uint64_t algorithmic_bytes);
 void prof_end(zk_ctx* c);
+void prof_add_bytes(zk_ctx* c, int tag, uint64_t bytes);   // to the tag's last record: bytes written that only the launch's result tells
 
 static inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 

@@ -2198,8 +2198,8 @@ int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int
     if (!max_chunks && a.tag_bits >= 14 && c->arena_size - c->arena_off > 64ull * chunks * (4 + 8 + 8) + (32ull << 20) + n / 16)
         ZK_TRY(arena_alloc(c, sizeof(u32) * 64 * chunks, (void**)&a.sub));
     ZK_HIP(c, hipMemsetAsync(c->d_scalars + 27, 0, 5 * sizeof(u64), c->stream));
-    // algorithmic bytes: every key read once (a 32-bit tag, or the whole key), one word written per distinct key -- the words are not
-    // counted yet when the launch is timed; the caller's n_out says how many (bench.py adds 8 bytes for each)
+    // algorithmic bytes: every key read once (a 32-bit tag, or the whole key), one word written per distinct key (added below, once
+    // the launch has said how many)
     prof_begin(c, ZK_PROF_RLE, (tags ? 4 : 8) * n);
     auto launch_one_per_cu = [&](const DedupeArgs& d) {
         const u32 grid = d.chunks < (u32)c->num_cus ? d.chunks : (u32)c->num_cus;
@@ -2266,6 +2266,7 @@ int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int
     ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 9, incl + chunks - 1, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     r->n_out = c->h_scalars[9];
+    prof_add_bytes(c, ZK_PROF_RLE, 8 * r->n_out);          // one word written per distinct key
     r->cuts = cuts; r->nwords = nwords; r->incl = incl; r->big = big; r->chunks = (uint32_t)chunks; r->pack = pack; r->work = work; r->sub = a.sub;
     if (n_in) *n_in = c->h_scalars[32];          // keys covered by the blocks that were counted
     return ZK_OK;

@@ -333,6 +333,7 @@ static int union_sum_t(zk_ctx* c, const u64* A, const CT* cA, u64 nA, const u64*
     ZK_HIP(c, hipMemcpyAsync(c->h_scalars, c->d_scalars, sizeof(u64) * 16, hipMemcpyDeviceToHost, c->stream));
     ZK_HIP(c, hipStreamSynchronize(c->stream));
     *n_out = c->h_scalars[9];
+    prof_add_bytes(c, ZK_PROF_UNION, (8 + sizeof(CT)) * *n_out);          // the entries written (the launch was opened with the bytes read)
     if (acgt_w) for (int b = 0; b < 4; b++) acgt_w[b] = c->h_scalars[b];
     return check_device_error(c);
 }
