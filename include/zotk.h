@@ -77,8 +77,9 @@ int zk_upload_async(zk_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 #define ZK_TUNE_PACKED_PAIRS 8   /* zk_kmerize / zk_mirror_expand: 1 (default) = (k-mer, count) pairs travel as one 64-bit word when the counts fit the bits above 2K */
 #define ZK_TUNE_WIDE_TILES 9     /* radix sort: 1 (default) = array passes over up to 3 * 2^30 keys use 16 K-key tiles, one workgroup per CU */
 #define ZK_TUNE_STREAM_PASS 10   /* the first sort pass of zk_kmerize / zk_sort_stream: 1 (default) = static stream ranges, whole 64-byte units written
-                                  * out of LDS (stream_pass.hip); 2 = the same with 32-byte units (measurements); 0 = the look-back pipeline */
-#define ZK_TUNE_STREAM_RANGES 11 /* ... the number of ranges the stream is cut into, one workgroup each (0 = one per CU, the default; <= 4096) */
+                                  * out of LDS (stream_pass.hip); 3 = the same, a tile's units leaving in two bursts (measurements; 2 is accepted and
+                                  * equals 1); 0 = the look-back pipeline.  Other values are refused */
+#define ZK_TUNE_STREAM_RANGES 11 /* ... the number of ranges the stream is cut into, one workgroup each (0 = two per CU, the default; <= 4096) */
 #define ZK_TUNE_TAG_WORDS 12     /* zk_kmerize: 1 (default) = the pass before the block dedupe writes 32-bit tags instead of whole keys when the key bits
                                   * below the blocks fit (K <= 25 after two passes); 0 = whole keys */
 #define ZK_TUNE_DEDUPE_VARIANT 13 /* the block dedupe of zk_kmerize at <= 32 key bits below the blocks: 0 (default) = dedupe2_kernel, two 512-thread

@@ -129,6 +129,37 @@ def test_kmer_table_merge_tree_matches_one_batch(ctx):
     assert h == {int(a): int(b) for a, b in zip(hv, hf)}
 
 
+def test_kmer_table_grows_after_a_slab_swap_when_memory_is_short(ctx, monkeypatch):
+    """The merge at the bottom of the stack swaps the two slabs, which leaves the scratch slab at the table slab's full size.  When
+    the table then has to grow with live entries and memory is short (old pair + new pair + that scratch), the scratch slab -- nothing
+    in it is live between merges -- is given up first.  Memory is made to look short (mem_info patched); the arrays stay the oracle's."""
+    from zotmer_amd.library import engine
+    engine.release_table_memory(ctx)
+    reads = synth.read_strings(synth.DEFAULT_SEED + 3, 0, 9000, 150, genome=0)          # no repeats: the table grows with every batch
+    want = zo.kmerize(25, reads)
+    t = engine.KmerTable(ctx, 25)
+    batches = [np.frombuffer(("".join(r + "\n" for r in reads[i:i + 1000])).encode(), dtype=np.uint8) for i in range(0, len(reads), 1000)]
+    for b in batches[:2]:
+        t.add_stream(b)          # two tables of one level: merged at the bottom of the stack -> the slabs swap
+    assert t.scratch.E > 0
+    real = ctx.mem_info
+    released = []
+    orig_release = engine.Slab.release
+
+    def release(self):
+        released.append(self.E)
+        orig_release(self)
+    monkeypatch.setattr(engine.Slab, "release", release)
+    monkeypatch.setattr(ctx, "mem_info", lambda: (1 << 20, real()[1]))          # "one MiB free": every comfortable size is refused
+    for b in batches[2:]:
+        t.add_stream(b)
+    monkeypatch.setattr(ctx, "mem_info", real)
+    assert released and released[0] > 0, "the scratch slab was never given up"
+    k, c, h = t.result()
+    assert np.array_equal(k, want["kmers"]) and np.array_equal(c, want["counts"]) and t.acgt == want["acgt"]
+    engine.release_table_memory(ctx)
+
+
 def _run(script, *args, timeout=900):
     r = subprocess.run([sys.executable, os.path.join(HERE, script)] + list(args), capture_output=True, text=True, timeout=timeout)
     return r

@@ -321,7 +321,15 @@ int zk_tune(zk_ctx* c, int what, int value) {
     if (what == ZK_TUNE_COMM_SELF_LOOP) { c->comm_self_loop = value ? 1 : 0; return ZK_OK; }
     if (what == ZK_TUNE_COMM_SELF_LOOP) { c->comm_self_loop = value ? 1 : 0; return ZK_OK; }
     if (what == ZK_TUNE_COMM_CHUNK) { c->comm_chunk_bytes = value > 0 ? (uint64_t)value : 0; return ZK_OK; }
-    if (what == ZK_TUNE_STREAM_PASS) { c->stream_pass = value < 0 ? 0 : value; return ZK_OK; }
+    if (what == ZK_TUNE_STREAM_PASS) {
+#ifdef ZK_PHASES
+        c->stream_pass = value < 0 ? 0 : value;          // (bits 8 and up: the measurement modes of tools/p0_phases.py)
+#else
+        if (value < 0 || value > 3) return fail(c, ZK_EINVAL, "stream pass variant %d (0, 1 or 3)", value);
+        c->stream_pass = value;
+#endif
+        return ZK_OK;
+    }
     if (what == ZK_TUNE_TAG_WORDS) { c->tag_words = value ? 1 : 0; return ZK_OK; }
     if (what == ZK_TUNE_DEDUPE_VARIANT) { c->dedupe_variant = value < 0 ? -1 : (value & 3); return ZK_OK; }
     if (what == ZK_TUNE_DEDUPE_BITS) { c->dedupe_bits = value < 0 ? 0 : value; return ZK_OK; }

@@ -27,13 +27,13 @@ struct zk_ctx {
     int side_div = 8;          // ... side list capacity = n / side_div (tests shrink it to force the fallback)
     int pairs_variant = 2;     // ... for (key, u32) pairs
     int stream_pass = 1;       // the first sort pass (from the base stream): 1 = static ranges, whole 64-byte units written from LDS
-                               // (stream_pass.hip; 2 = 32-byte units, for measurements), 0 = the look-back pipeline
+                               // (stream_pass.hip; 3 = a tile's units leave in two bursts, for measurements), 0 = the look-back pipeline
     int tag_words = 1;         // zk_kmerize, block dedupe after two passes with at most 32 key bits below the blocks: the second pass writes
                                // only those bits, as 32-bit tags (radix_sort.hip); 0 = whole keys
     int dedupe_variant = 0;    // block dedupe at <= 32 tag bits: dedupe2_kernel's variant (dedupe2.hip), -1 = dedupe_kernel alone
     int dedupe_limit = 65536;  // ... blocks of this many keys or more go to dedupe_kernel (16-bit counts in dedupe2_kernel's table)
     int dedupe_bits = 0;       // tests: > 0 = the block dedupe with this many block bits whatever the input's size (pipeline.hip)
-    int stream_ranges = 0;     // ... ranges the stream is cut into (0 = one per CU; tests use a few so that a range has many tiles)
+    int stream_ranges = 0;     // ... ranges the stream is cut into (0 = two per CU; tests use a few so that a range has many tiles)
 
     // workspace arena: a bump allocator reset at the start of every API call
     char* arena = nullptr;

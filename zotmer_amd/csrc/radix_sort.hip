@@ -22,6 +22,7 @@
 // The geometry (threads per workgroup, keys per thread, digit bits) is a compile-time Cfg; a few
 // are instantiated and zk_tune(ZK_TUNE_SORT_VARIANT) picks one (default chosen from
 // measurements on MI355X).
+#include <stdlib.h>
 #include "internal.hpp"
 #include "encode_tile.hpp"
 #include "dedupe.hpp"
@@ -1979,6 +1980,11 @@ struct Sorter {
         ZK_HIP(c, hipStreamSynchronize(c->stream));
         const uint64_t n = c->h_scalars[8];
         if (acgt) for (int b = 0; b < 4; b++) acgt[b] = c->h_scalars[b];
+#ifdef ZK_PHASES
+        // measurement of the histogram kernel with fewer LDS adds than it needs (tools/p0_phases.py): its counts are wrong, nothing
+        // may be sorted by them
+        if (const char* e = getenv("ZK_HIST_ATOMICS")) if (atoi(e) != 2) { *n_keys = 0; return ZK_OK; }
+#endif
         *n_keys = n;
         if (n > cap) return fail(c, ZK_ENOSPC, "sort buffers hold %llu keys, the stream has %llu", (unsigned long long)cap, (unsigned long long)n);
         if (n == 0) return ZK_OK;
@@ -2002,7 +2008,9 @@ struct Sorter {
             const bool uniform = first_nl < 0x7fffffffull && src.n_bytes % (first_nl + 1) == 0 && bad == 0 && nl == src.n_bytes / (first_nl + 1);
             ZK_TRY(stream_pass0(c, src.n_bytes, src.K, src.mode, plan.shift[0], plan.bits[0], ghist, srows, first_nl, uniform, buf_a, n,
                                 c->stream_pass));
+#ifdef ZK_PHASES
             if (c->stream_pass >> 8) { *n_keys = 0; return ZK_OK; }          // measurement modes of the pass (diagnostic build, tools/p0_phases.py): nothing is counted
+#endif
         } else
         if constexpr (C::PIPE && C::ITEMS == 16 && PipeSmem<C>::IMG_FITS && C::BLOCK <= 512) {
             // Uniform records (checked by the histogram kernel: the only newlines are one every `rec` bytes): tiles follow

@@ -20,6 +20,7 @@
 #include "internal.hpp"
 #include "encode_tile.hpp"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace zk {
@@ -164,6 +165,7 @@ struct SHistArgs {
     u32 ranges, split;            // grid = ranges * split: workgroup (w, s) takes every split-th tile of range w
     u32* gcodes;                  // [ceil(n_bytes / 16)] the stream's 2-bit image, 16 bases per word (first base on top) ...
     u16* gvalid;                  // ... and which of them are bases: the pass reads these instead of encoding the bytes again
+    int dbg_atomics;              // diagnostic build (-DZK_PHASES) only: LDS adds per window (2 = as in the product)
 };
 
 // HI: every digit (and the sample test) looks only at key bits >= 32: the strands are compared on the high words alone --
@@ -294,8 +296,15 @@ __global__ __launch_bounds__(SH_BLOCK, 4) void stream_hist_kernel(SHistArgs h) {
                 kd = canon ? (x < xb ? x : xb) : x;
             }
             if constexpr (TWO && HI) {
+#ifdef ZK_PHASES          // measurement (results are wrong): ZK_HIST_ATOMICS = 0 / 1 of the two adds per window -- what bounds the kernel, the
+                          // atomic unit or the window arithmetic? (tools/p0_phases.py, profiles/r04/hist_atomics.json)
+                if (h.dbg_atomics >= 1) atomicAdd(&bins[__builtin_amdgcn_ubfe(kd, sh0, nb0)], inc);
+                if (h.dbg_atomics >= 2) atomicAdd(&bins[base1 + __builtin_amdgcn_ubfe(kd, sh1, nb1)], inc);
+                if (h.dbg_atomics == 0) a0 += kd & inc;          // (the key stays live)
+#else
                 atomicAdd(&bins[__builtin_amdgcn_ubfe(kd, sh0, nb0)], inc);
                 atomicAdd(&bins[base1 + __builtin_amdgcn_ubfe(kd, sh1, nb1)], inc);
+#endif
             } else if constexpr (TWO) {
                 atomicAdd(&bins[(u32)(kd >> sh0) & dm0], inc);
                 atomicAdd(&bins[base1 + ((u32)(kd >> sh1) & dm1)], inc);
@@ -376,7 +385,7 @@ struct P0Args {
     const u64* offs;      // [ranges][1 << bits]
     const u32* rows;      // [ranges][1 << bits]: checked against what the pass wrote
     u64* kout;
-    u64 n;                // keys in all: nothing is ever stored at or beyond it
+    u64 n;                // keys in all (every digit's piece ends at or before it; a store never leaves its digit's piece)
     u32* err;
     int split_stores;     // 1: a tile's units leave in two bursts (see the kernel)
     int dbg_mode;         // diagnostic build (-DZK_PHASES) only, measurements (results are wrong): 1 = no stores, 2 = after a range's first tile only the stores (its keys again and again)
@@ -419,6 +428,7 @@ struct P0Smem {
     u16 off[RADIX];                // where the digit's keys start in exch
     u16 nu[RADIX];                 // units of the digit
     u32 nunits;
+    u32 anybad;                    // some digit has more keys than its piece holds (the histogram and the pass disagree): no further stores
 };
 
 // One digit per thread (RADIX == P0_BLOCK): the digit's output cursor and its left-over keys' place are that thread's registers.
@@ -456,6 +466,7 @@ __global__ __launch_bounds__(P0_BLOCK, 4) void stream_pass0_kernel(P0Args a) {
     u32 bad = 0;                                                             // more keys of the digit than the histogram had counted
     u32 flen_dbg = 0;
     sm.cnt[tid] = 0;
+    if (tid == 0) sm.anybad = 0;
     // this thread's windows inside a tile: NW consecutive ones from tile position p0 on
     u32 p0 = (u32)NW * tid, wlim = (1u << NW) - 1u;          // wlim: which of them exist at all
     if (a.by_record) {
@@ -580,7 +591,7 @@ __global__ __launch_bounds__(P0_BLOCK, 4) void stream_pass0_kernel(P0Args a) {
             const u32 inc = wave_incl_scan_dpp(tot);
             O = before + inc - tot;
             u64 end = F + tot;
-            if (end > Fend) { bad = 1; end = Fend > F ? Fend : F; }          // never beyond the digit's piece (then the error word is set)
+            if (end > Fend) { bad = 1; sm.anybad = 1; end = Fend > F ? Fend : F; }          // never beyond the digit's piece (then the error word is set)
             u64 Eo = last ? end : (end & ~(u64)(G - 1));
             if (Eo < F) Eo = F;
             flen = (u32)(Eo - F);
@@ -607,11 +618,11 @@ __global__ __launch_bounds__(P0_BLOCK, 4) void stream_pass0_kernel(P0Args a) {
             flen_dbg = flen;
             // this digit's units
             u32 slot = O, left = flen;
-            if (head) { sm.units[U++] = unit_pack(slot, head, (u32)tid); slot += head; left -= head; }
+            if (head) { if (U < (u32)S::UNITS) sm.units[U] = unit_pack(slot, head, (u32)tid); U++; slot += head; left -= head; }
             while (left) {
                 const u32 len = left < (u32)G ? left : (u32)G;
-                sm.units[U++] = unit_pack(slot, len, (u32)tid);
-                slot += len; left -= len;
+                if (U < (u32)S::UNITS) sm.units[U] = unit_pack(slot, len, (u32)tid);
+                U++; slot += len; left -= len;
             }
             F += flen;
         }
@@ -622,10 +633,15 @@ __global__ __launch_bounds__(P0_BLOCK, 4) void stream_pass0_kernel(P0Args a) {
             u32 at[NW];
 #pragma unroll
             for (int i = 0; i < NW; i++) at[i] = sm.off[digit(key[i])];
+            // (a slot at or beyond CAP can only come up when the pass finds more keys of a digit than the histogram counted -- `bad`, the
+            // launch ends with ZK_DERR_MISMATCH -- and then goes to the lane's dead slot: nothing is ever written outside exch)
 #pragma unroll
-            for (int i = 0; i < NW; i++) sm.exch[((live >> i) & 1u) ? at[i] + rk[i] : (u32)S::CAP + (u32)lane] = key[i];
+            for (int i = 0; i < NW; i++) {
+                const u32 slot = at[i] + rk[i];
+                sm.exch[(((live >> i) & 1u) && slot < (u32)S::CAP) ? slot : (u32)S::CAP + (u32)lane] = key[i];
+            }
 #pragma unroll
-            for (int j = 0; j < G - 1; j++) sm.exch[(u32)j < nck ? O + j : (u32)S::CAP + (u32)lane] = ck[j];
+            for (int j = 0; j < G - 1; j++) sm.exch[((u32)j < nck && O + j < (u32)S::CAP) ? O + j : (u32)S::CAP + (u32)lane] = ck[j];
             nck = tot - flen;
             ctail = O + flen;
         }
@@ -642,7 +658,7 @@ __global__ __launch_bounds__(P0_BLOCK, 4) void stream_pass0_kernel(P0Args a) {
         // ---- whole units out: the first half now, the second after the next tile's keys are made (what they read stays as it is
         // until that tile's scan and park): two bursts of stores per tile instead of one, the other workgroup of the CU fills the gaps
         {
-            const u32 nunits = sm.nunits;
+            const u32 nunits = (sm.anybad || sm.nunits > (u32)S::UNITS) ? 0u : sm.nunits;          // (after `bad` the list is not to be trusted: nothing leaves, the launch reports ZK_DERR_MISMATCH)
             const u32 half = (P0_MODE == 2 || !a.split_stores) ? nunits : (nunits / 2 + 127u) & ~127u;
             store_units(0, half < nunits ? half : nunits, std::integral_constant<int, 4>());
             held = half < nunits ? half : nunits; held_end = nunits;
@@ -682,6 +698,10 @@ int stream_hist(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, 
     h.sample = sample; h.sample_n = sample_n; h.sample_cap = sample_cap; h.sample_shift = sample_shift; h.sample_value = sample_value;
     h.ranges = (u32)stream_ranges(c);
     h.split = 4;
+    h.dbg_atomics = 2;
+#ifdef ZK_PHASES
+    if (const char* e = getenv("ZK_HIST_ATOMICS")) h.dbg_atomics = atoi(e);
+#endif
     const u32 r0 = 1u << plan.bits[0];
     const uint64_t nchunks = (n_bytes + 15) / 16;
     u32* rows; u64* offs;

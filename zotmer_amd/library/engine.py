@@ -90,8 +90,10 @@ class Slab:
     def __init__(self, ctx):
         self.ctx, self.k, self.c, self.E = ctx, None, None, 0
 
-    def ensure(self, need, live=0, target=None):
-        """make room for `need` entries, preserving the first `live`; `target` (>= need) is the size to grow to if it fits"""
+    def ensure(self, need, live=0, target=None, spare=None):
+        """make room for `need` entries, preserving the first `live`; `target` (>= need) is the size to grow to if it fits.
+        spare: another slab with nothing live in it (the merge scratch between merges) -- given up first when growing with live
+        entries would otherwise not fit (old pair + new pair + a scratch that a slab swap has left at the table's full size)"""
         if need <= self.E:
             return
         ctx = self.ctx
@@ -100,6 +102,8 @@ class Slab:
         room = free + (0 if live else 12 * self.E)
         if 12 * want + (1 << 30) > room:                      # the comfortable size does not fit: take exactly what is needed
             want = int(need)
+            if live and spare is not None and spare.E and 12 * want + (1 << 30) > room:
+                spare.release()                               # ... and the scratch slab's memory with it (it regrows at the next merge)
         with _Phase(ctx, "table memory -> %d entries" % want):
             if not live:
                 self.k = self.c = None
@@ -214,7 +218,7 @@ class KmerTable:
             acgt = ctx.stream_acgt(d, self.K)
             d, _, _ = ctx.capture_filter(d, self.K, self.baits)
         while True:
-            slab.ensure(self.top + est, self.top, self._slab_target(self.top + est))
+            slab.ensure(self.top + est, self.top, self._slab_target(self.top + est), spare=self.scratch)
             out = (slab.k.view(est, self.top), slab.c.view(est, self.top))
             try:
                 with _Phase(ctx, "zk_kmerize"):
