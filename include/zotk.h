@@ -90,6 +90,10 @@ int zk_upload_async(zk_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
 #define ZK_TUNE_DEDUPE_BITS 15   /* tests: zk_kmerize takes the block dedupe with this many block bits (a whole number of 9-bit passes, e.g. 18)
                                   * whatever the size of the input, so that small oracle-checked inputs run two passes, tags and tiny blocks; 0 = by size (default) */
 #define ZK_TUNE_COMM_CHUNK 6     /* zk_all_to_all_v: bytes per message and round (0 = 256 MiB, the default) */
+#define ZK_TUNE_TAG_PASS 17      /* zk_kmerize, the two-pass plan with tags: 1 = pass 0 writes the keys as two arrays (low words, next digits: 6 bytes a key)
+                                  * and the second pass is a count / scan / scatter over static segments that writes whole 64-byte units of tags
+                                  * (tag_pass.hip); 0 (default) = whole keys and the look-back pipeline.  Same result either way; measured slower
+                                  * in all (profiles/r04/tag_pass_ab.json: the second pass gains 5 ms, pass 0 loses 8.5) */
 #define ZK_TUNE_COMM_SELF_LOOP 16 /* tests: 1 = the piece a rank keeps goes through grouped ncclSend / ncclRecv to itself, in the same rounds as
                                   * the other pieces (instead of a device copy), and zk_allreduce_u64 calls ncclAllReduce with one rank too:
                                   * the RCCL data path of zk_comm_* executed on a box with one GPU; 0 (default) */

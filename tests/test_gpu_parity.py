@@ -352,14 +352,16 @@ def test_kmerize_forced_block_dedupe(ctx, K):
                             ("big_block", big)):
             want = zo.kmerize(K, reads)
             d = ctx.upload_stream(stream_of(reads))
-            for tag_words, variant, limit in ((1, 0, 65536), (0, 0, 65536), (1, 2, 65536), (1, -1, 65536), (1, 0, 6), (0, 2, 6)):
-                ctx.tune(dedupe_bits=18, tag_words=tag_words, dedupe_variant=variant, dedupe_limit=limit)
+            # tag_pass: the tags written by tag_pass.hip's pass over static segments (pass 0 leaves two arrays), or by the look-back pipeline
+            for tag_words, variant, limit, tag_pass in ((1, 0, 65536, 1), (1, 0, 65536, 0), (0, 0, 65536, 1), (1, 2, 65536, 1), (1, -1, 65536, 0),
+                                                       (1, -1, 65536, 1), (1, 0, 6, 1), (0, 2, 6, 0)):
+                ctx.tune(dedupe_bits=18, tag_words=tag_words, dedupe_variant=variant, dedupe_limit=limit, tag_pass=tag_pass)
                 k, c, st = ctx.kmerize(d, K)
-                assert np.array_equal(k.to_host(), want["kmers"]), (name, tag_words, variant, limit)
-                assert np.array_equal(c.to_host(), want["counts"]), (name, tag_words, variant, limit)
+                assert np.array_equal(k.to_host(), want["kmers"]), (name, tag_words, variant, limit, tag_pass)
+                assert np.array_equal(c.to_host(), want["counts"]), (name, tag_words, variant, limit, tag_pass)
                 assert list(st.acgt) == want["acgt"] and st.n_unique == len(want["kmers"])
     finally:
-        ctx.tune(dedupe_bits=0, tag_words=1, dedupe_variant=0, dedupe_limit=65536)
+        ctx.tune(dedupe_bits=0, tag_words=1, dedupe_variant=0, dedupe_limit=65536, tag_pass=0)
 
 
 @pytest.mark.parametrize("K", [4, 12, 24, 25, 31, 32])

@@ -32,6 +32,9 @@ struct zk_ctx {
                                // only those bits, as 32-bit tags (radix_sort.hip); 0 = whole keys
     int dedupe_variant = 0;    // block dedupe at <= 32 tag bits: dedupe2_kernel's variant (dedupe2.hip), -1 = dedupe_kernel alone
     int dedupe_limit = 65536;  // ... blocks of this many keys or more go to dedupe_kernel (16-bit counts in dedupe2_kernel's table)
+    int tag_pass = 0;          // ... 1 = the pass that writes them is tag_pass.hip's count / scan / scatter over static segments, reading pass 0's
+                               // keys as two arrays (6 bytes a key); 0 (default) = the look-back pipeline over whole keys.  Measured
+                               // (profiles/r04/tag_pass_ab.json): the pass 25.0 -> 17.4 + 2.2 ms, but pass 0 21.3 -> 29.8 ms (half-line units)
     int dedupe_bits = 0;       // tests: > 0 = the block dedupe with this many block bits whatever the input's size (pipeline.hip)
     int stream_ranges = 0;     // ... ranges the stream is cut into (0 = two per CU; tests use a few so that a range has many tiles)
 
@@ -171,8 +174,13 @@ struct StreamRows { u32* rows = nullptr; u64* offs = nullptr; u32 ranges = 0, ra
 int stream_hist(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, const PassPlan& plan, u64* ghist, u32 gstride,
                 u64* d_acgt, u64* d_n, u64* rec_info, u64* sample, u32 sample_cap, int sample_shift, u64 sample_value, u32* sample_n,
                 void* image_room, uint64_t image_room_bytes, StreamRows* out);
+// planes (or null): the pass writes the keys' low 32 bits (u32[n] at kout) and the next pass's digit, (key >> shift) & (2^bits - 1),
+// as u16[n] at dig -- 6 bytes a key instead of 8; stream_pass1 takes them from there
+struct StreamPlanes { u16* dig; int shift, bits; };
 int stream_pass0(zk_ctx* c, uint64_t n_bytes, int K, int mode, int shift, int bits, const u64* ghist0, const StreamRows& rows,
-                 uint64_t first_nl, bool uniform, u64* kout, uint64_t n, int variant);
+                 uint64_t first_nl, bool uniform, u64* kout, uint64_t n, int variant, const StreamPlanes* planes = nullptr);
+// tag_pass.hip: the second pass of the two-pass plan over pass 0's two arrays; writes the tags ordered by (d1, d0) and the blocks' starts
+int stream_pass1(zk_ctx* c, const u32* tags, const u16* dig, uint64_t n, const u64* ghist0, uint32_t radix0, int bits1, u32* tout, u64* cuts);
 // select.hip
 int trim(zk_ctx* c, const u64* keys, const void* cnts, int cbits, uint64_t n, u64 lo, u64 hi, u64* ok, void* oc,
          uint64_t cap, uint64_t* n_out);

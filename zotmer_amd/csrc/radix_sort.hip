@@ -2006,6 +2006,23 @@ struct Sorter {
         if (ranged) {
             const uint64_t first_nl = c->h_scalars[20], nl = c->h_scalars[21], bad = c->h_scalars[22];
             const bool uniform = first_nl < 0x7fffffffull && src.n_bytes % (first_nl + 1) == 0 && bad == 0 && nl == src.n_bytes / (first_nl + 1);
+            // The usual plan (two passes over the top bits, tags for the block dedupe): pass 0 leaves the keys as two arrays, low words and
+            // next digits, 6 bytes a key, and the second pass is tag_pass.hip's count / scan / scatter over static segments -- done here.
+            const uint64_t n_pad = ((n + 63) & ~63ull) + 64;
+            const bool planes = c->tag_pass && src.tags && plan.passes == 2 && plan.shift[0] == 32 && plan.bits[0] == 9 && plan.bits[1] == 9 &&
+                                src.mode == ZK_KEYS_CANONICAL && 2 * src.K > 32 && n >= 4096 && 4 * n_pad + 2 * n + 64 <= 8 * cap;
+            if (planes) {
+                StreamPlanes pl{(u16*)((char*)buf_a + 4 * n_pad), plan.shift[1], plan.bits[1]};
+                ZK_TRY(stream_pass0(c, src.n_bytes, src.K, src.mode, plan.shift[0], plan.bits[0], ghist, srows, first_nl, uniform, buf_a, n,
+                                    c->stream_pass, &pl));
+                const uint64_t blocks = 1ull << (plan.bits[0] + plan.bits[1]);
+                u64* cuts;
+                ZK_TRY(arena_alloc(c, sizeof(u64) * (blocks + 1), (void**)&cuts));
+                ZK_TRY(stream_pass1(c, (const u32*)buf_a, pl.dig, n, ghist, 1u << plan.bits[0], plan.bits[1], (u32*)buf_b, cuts));
+                src.tags->cuts = cuts; src.tags->blocks = (uint32_t)blocks; src.tags->written = true;
+                *result = buf_b;
+                return ZK_OK;
+            }
             ZK_TRY(stream_pass0(c, src.n_bytes, src.K, src.mode, plan.shift[0], plan.bits[0], ghist, srows, first_nl, uniform, buf_a, n,
                                 c->stream_pass));
 #ifdef ZK_PHASES

@@ -385,6 +385,9 @@ struct P0Args {
     const u64* offs;      // [ranges][1 << bits]
     const u32* rows;      // [ranges][1 << bits]: checked against what the pass wrote
     u64* kout;
+    u16* dig_out;         // PLANES: the next pass's digit of every key, (key >> dig_shift) & dig_mask (kout then holds the keys' low words, u32)
+    int dig_shift;
+    u32 dig_mask;
     u64 n;                // keys in all (every digit's piece ends at or before it; a store never leaves its digit's piece)
     u32* err;
     int split_stores;     // 1: a tile's units leave in two bursts (see the kernel)
@@ -434,7 +437,9 @@ struct P0Smem {
 // One digit per thread (RADIX == P0_BLOCK): the digit's output cursor and its left-over keys' place are that thread's registers.
 // CANON: the key is min(x, rc x) (else x).  FAST: 2 K > 32 and the digit lies in the key's high word (the usual plan): no mask on the
 // low words, the digit is one bit-field extract.
-template <int RBITS, int G, bool CANON, bool FAST>
+// PLANES: the keys leave as two arrays -- the low 32 bits (a u32 at kout) and the next pass's digit (a u16 at dig_out), same index --
+// instead of whole keys: the 9 bits of this pass's digit are said by the key's place, the next pass reads 6 bytes a key, not 8.
+template <int RBITS, int G, bool CANON, bool FAST, bool PLANES = false>
 __global__ __launch_bounds__(P0_BLOCK, 4) void stream_pass0_kernel(P0Args a) {
     using S = P0Smem<RBITS, G>;
     constexpr int RADIX = S::RADIX, NW = P0_NW, BLOCK = P0_BLOCK;
@@ -529,6 +534,90 @@ __global__ __launch_bounds__(P0_BLOCK, 4) void stream_pass0_kernel(P0Args a) {
             }
         }
     };
+    // PLANES: the same units as two arrays.  A lane writes 16 bytes here too: half a unit's low words (four tags), or a whole unit's
+    // eight next digits -- first every half unit, then every unit.  (Two tags and two digits per lane, the lanes of the whole-key
+    // stores: 30.1 ms against 21.3 for whole keys -- twice the store instructions, of 8 and 4 bytes.)
+    auto store_units_planes = [&](u32 first, u32 end) {
+        constexpr int NF = 4;
+        struct __attribute__((packed, aligned(4))) Tag4 { u32 a, b, c, d; };
+        struct __attribute__((packed, aligned(2))) Dig8 { u32 a, b, c, d; };
+        u32* const tplane = reinterpret_cast<u32*>(a.kout);
+        // ---- low words: work item = (unit, half) ----
+        for (u32 base = 2 * first; base < 2 * end; base += NF * BLOCK) {
+            u32 e4[NF];
+            u32 t4[NF][4];
+            u64 b4[NF];
+#pragma unroll
+            for (int g = 0; g < NF; g++) {
+                const u32 it = base + g * BLOCK + (u32)tid, u = it >> 1;
+                e4[g] = sm.units[u < (u32)S::UNITS ? u : 0u];
+            }
+#pragma unroll
+            for (int g = 0; g < NF; g++) asm volatile("" : "+v"(e4[g]));
+#pragma unroll
+            for (int g = 0; g < NF; g++) {
+                const u32 it = base + g * BLOCK + (u32)tid;
+                const u32 sl = (e4[g] & 0x3fffu) + 4u * (it & 1u);
+#pragma unroll
+                for (int q = 0; q < 4; q++) t4[g][q] = (u32)sm.exch[sl + q];          // (sl + q < CAP + 8: slots past a unit's end are read, never stored)
+                b4[g] = sm.gbase[(e4[g] >> 18) & (u32)(RADIX - 1)];
+            }
+#pragma unroll
+            for (int g = 0; g < NF; g++) asm volatile("" : "+v"(t4[g][0]), "+v"(t4[g][1]), "+v"(t4[g][2]), "+v"(t4[g][3]), "+v"(b4[g]));
+#pragma unroll
+            for (int g = 0; g < NF; g++) {
+                const u32 it = base + g * BLOCK + (u32)tid, h4 = 4u * (it & 1u);
+                const u32 len = ((e4[g] >> 14) & 15u) + 1u;
+                u32* dst = tplane + (b4[g] + (e4[g] & 0x3fffu) + h4);
+                if (it < 2 * end && P0_MODE != 1) {
+                    if (h4 + 4 <= len) { Tag4 v; v.a = t4[g][0]; v.b = t4[g][1]; v.c = t4[g][2]; v.d = t4[g][3]; *reinterpret_cast<Tag4*>(dst) = v; }
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 3; q++) if (h4 + q < len) dst[q] = t4[g][q];
+                    }
+                }
+            }
+        }
+        // ---- next digits: work item = unit ----
+        for (u32 base = first; base < end; base += NF * BLOCK) {
+            u32 e4[NF];
+            u32 d8[NF][4];
+            u64 b4[NF];
+#pragma unroll
+            for (int g = 0; g < NF; g++) {
+                const u32 u = base + g * BLOCK + (u32)tid;
+                e4[g] = sm.units[u < (u32)S::UNITS ? u : 0u];
+            }
+#pragma unroll
+            for (int g = 0; g < NF; g++) asm volatile("" : "+v"(e4[g]));
+#pragma unroll
+            for (int g = 0; g < NF; g++) {
+                const u32 sl = e4[g] & 0x3fffu;
+                u32 hw[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) hw[q] = (u32)(sm.exch[sl + q] >> 32);
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    d8[g][q] = ((hw[2 * q] >> (a.dig_shift - 32)) & a.dig_mask) | (((hw[2 * q + 1] >> (a.dig_shift - 32)) & a.dig_mask) << 16);
+                b4[g] = sm.gbase[(e4[g] >> 18) & (u32)(RADIX - 1)];
+            }
+#pragma unroll
+            for (int g = 0; g < NF; g++) asm volatile("" : "+v"(d8[g][0]), "+v"(d8[g][1]), "+v"(d8[g][2]), "+v"(d8[g][3]), "+v"(b4[g]));
+#pragma unroll
+            for (int g = 0; g < NF; g++) {
+                const u32 u = base + g * BLOCK + (u32)tid;
+                const u32 len = ((e4[g] >> 14) & 15u) + 1u;
+                u16* dst = a.dig_out + (b4[g] + (e4[g] & 0x3fffu));
+                if (u < end && P0_MODE != 1) {
+                    if (len == 8) { Dig8 v; v.a = d8[g][0]; v.b = d8[g][1]; v.c = d8[g][2]; v.d = d8[g][3]; *reinterpret_cast<Dig8*>(dst) = v; }
+                    else {
+#pragma unroll
+                        for (int q = 0; q < 7; q++) if ((u32)q < len) dst[q] = (u16)(d8[g][q >> 1] >> (16 * (q & 1)));
+                    }
+                }
+            }
+        }
+    };
     u32 held = 0, held_end = 0;          // units [held, held_end) of the last tile are still to be stored
     for (u32 t = 0; t < ntile; t++) {
         const u64 T0 = B + (u64)t * tile_bytes;
@@ -574,7 +663,7 @@ __global__ __launch_bounds__(P0_BLOCK, 4) void stream_pass0_kernel(P0Args a) {
         for (int i = 0; i < NW; i++) {
             rk[i] = atomicAdd(&sm.cnt[((live >> i) & 1u) ? digit(key[i]) : (u32)RADIX + (u32)lane], 1u);
         }
-        if (held < held_end) store_units(held, held_end, std::integral_constant<int, 2>());          // (the tile's keys and ranks are live here: two in flight)
+        if constexpr (!PLANES) { if (held < held_end) store_units(held, held_end, std::integral_constant<int, 2>()); }          // (the tile's keys and ranks are live here: two in flight; PLANES never holds units back)
         held = held_end = 0;
         P0_PHASE(0);          // keys made, ranks asked for (and the second half of the last tile's units out)
         __syncthreads();
@@ -659,15 +748,16 @@ __global__ __launch_bounds__(P0_BLOCK, 4) void stream_pass0_kernel(P0Args a) {
         // until that tile's scan and park): two bursts of stores per tile instead of one, the other workgroup of the CU fills the gaps
         {
             const u32 nunits = (sm.anybad || sm.nunits > (u32)S::UNITS) ? 0u : sm.nunits;          // (after `bad` the list is not to be trusted: nothing leaves, the launch reports ZK_DERR_MISMATCH)
-            const u32 half = (P0_MODE == 2 || !a.split_stores) ? nunits : (nunits / 2 + 127u) & ~127u;
-            store_units(0, half < nunits ? half : nunits, std::integral_constant<int, 4>());
+            const u32 half = (PLANES || P0_MODE == 2 || !a.split_stores) ? nunits : (nunits / 2 + 127u) & ~127u;
+            if constexpr (PLANES) store_units_planes(0, half < nunits ? half : nunits);
+            else store_units(0, half < nunits ? half : nunits, std::integral_constant<int, 4>());
             held = half < nunits ? half : nunits; held_end = nunits;
         }
         P0_PHASE(6);          // stores issued
         __syncthreads();          // the next image is whole; nobody still reads what the next tile's scan and park rewrite
         P0_PHASE(7);          // ... waiting
     }
-    if (held < held_end) store_units(held, held_end, std::integral_constant<int, 2>());
+    if constexpr (!PLANES) { if (held < held_end) store_units(held, held_end, std::integral_constant<int, 2>()); }
     if (a.dbg && tid == 0) {
         for (int k = 0; k < 8; k++) a.dbg[(u64)w * 16 + k] = (u64)ph[k];
         a.dbg[(u64)w * 16 + 8] = ntile;
@@ -734,7 +824,7 @@ int stream_hist(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, 
 
 // after the exclusive prefix of pass 0's digits is in ghist0 and the host has read the verdict on the records
 int stream_pass0(zk_ctx* c, uint64_t n_bytes, int K, int mode, int shift, int bits, const u64* ghist0, const StreamRows& rows,
-                 uint64_t first_nl, bool uniform, u64* kout, uint64_t n, int variant) {
+                 uint64_t first_nl, bool uniform, u64* kout, uint64_t n, int variant, const StreamPlanes* planes) {
     if (bits < 1 || bits > 9 || (1u << bits) != rows.radix) return fail(c, ZK_EINTERNAL, "stream_pass0: %d digit bits, rows of %u", bits, rows.radix);
     hipLaunchKernelGGL(rows_scan_kernel, dim3((rows.radix + 255) / 256), dim3(256), 0, c->stream, rows.rows, ghist0, rows.ranges, rows.radix, rows.offs);
     P0Args a = {};
@@ -743,6 +833,16 @@ int stream_pass0(zk_ctx* c, uint64_t n_bytes, int K, int mode, int shift, int bi
     a.by_record = (uniform && a.tl.rec) ? 1 : 0;
     a.shift = shift; a.bits = bits; a.offs = rows.offs; a.rows = rows.rows; a.kout = kout; a.n = n; a.err = c->d_err; a.dbg = c->dbg; a.dbg_mode = variant >> 8; a.split_stores = (variant & 0xff) == 3;          // measured: 10.05 vs 8.73 ms on 20 M reads -- the held-back half sits in the key phase's way
     const bool canon = mode == ZK_KEYS_CANONICAL, fast = 2 * K > 32 && shift >= 32;
+    if (planes) {
+        // two arrays instead of whole keys (the next pass reads them: stream_pass1): only the usual plan asks for it
+        if (!canon || !fast) return fail(c, ZK_EINTERNAL, "stream_pass0: planes need the canonical fast plan");
+        a.dig_out = planes->dig; a.dig_shift = planes->shift; a.dig_mask = (1u << planes->bits) - 1u;
+        prof_begin(c, ZK_PROF_PASS_STREAM, n_bytes + 6 * n);
+        hipLaunchKernelGGL((stream_pass0_kernel<9, 8, true, true, true>), dim3(rows.ranges), dim3(P0_BLOCK), 0, c->stream, a);
+        prof_end(c);
+        ZK_HIP(c, hipGetLastError());
+        return ZK_OK;
+    }
     prof_begin(c, ZK_PROF_PASS_STREAM, n_bytes + 8 * n);
     if (canon && fast) hipLaunchKernelGGL((stream_pass0_kernel<9, 8, true, true>), dim3(rows.ranges), dim3(P0_BLOCK), 0, c->stream, a);
     else if (canon) hipLaunchKernelGGL((stream_pass0_kernel<9, 8, true, false>), dim3(rows.ranges), dim3(P0_BLOCK), 0, c->stream, a);
