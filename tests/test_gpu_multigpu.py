@@ -131,8 +131,9 @@ def test_kmer_table_merge_tree_matches_one_batch(ctx):
 
 def test_kmer_table_grows_after_a_slab_swap_when_memory_is_short(ctx, monkeypatch):
     """The merge at the bottom of the stack swaps the two slabs, which leaves the scratch slab at the table slab's full size.  When
-    the table then has to grow with live entries and memory is short (old pair + new pair + that scratch), the scratch slab -- nothing
-    in it is live between merges -- is given up first.  Memory is made to look short (mem_info patched); the arrays stay the oracle's."""
+    the table then has to grow with live entries and the allocation fails (old pair + new pair + that scratch do not fit together),
+    the scratch slab -- nothing in it is live between merges -- is given up and the allocation tried again.  The failure is injected
+    (zk_alloc refuses while the scratch slab holds memory); the arrays stay the oracle's."""
     from zotmer_amd.library import engine
     engine.release_table_memory(ctx)
     reads = synth.read_strings(synth.DEFAULT_SEED + 3, 0, 9000, 150, genome=0)          # no repeats: the table grows with every batch
@@ -142,19 +143,24 @@ def test_kmer_table_grows_after_a_slab_swap_when_memory_is_short(ctx, monkeypatc
     for b in batches[:2]:
         t.add_stream(b)          # two tables of one level: merged at the bottom of the stack -> the slabs swap
     assert t.scratch.E > 0
-    real = ctx.mem_info
-    released = []
-    orig_release = engine.Slab.release
+    refused, released = [], []
+    real_empty, orig_release = ctx.empty, engine.Slab.release
+
+    def empty(n, dtype):
+        if t.scratch.E and n > 300000 and np.dtype(dtype) == np.uint64:          # a grow of the table slab while the scratch slab holds memory
+            refused.append(n)
+            raise native.ZotkError(-2, "injected: out of device memory")
+        return real_empty(n, dtype)
 
     def release(self):
         released.append(self.E)
         orig_release(self)
     monkeypatch.setattr(engine.Slab, "release", release)
-    monkeypatch.setattr(ctx, "mem_info", lambda: (1 << 20, real()[1]))          # "one MiB free": every comfortable size is refused
+    monkeypatch.setattr(ctx, "empty", empty)
     for b in batches[2:]:
         t.add_stream(b)
-    monkeypatch.setattr(ctx, "mem_info", real)
-    assert released and released[0] > 0, "the scratch slab was never given up"
+    monkeypatch.setattr(ctx, "empty", real_empty)
+    assert refused and released and released[0] > 0, "the scratch slab was never given up"
     k, c, h = t.result()
     assert np.array_equal(k, want["kmers"]) and np.array_equal(c, want["counts"]) and t.acgt == want["acgt"]
     engine.release_table_memory(ctx)

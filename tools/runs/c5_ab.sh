@@ -1,0 +1,12 @@
+set -o pipefail
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out
+for t in "wide_tiles=1" "short_sort=1"; do
+  ZOT_TUNE=$t timeout -k 10 300 python bench.py --no-cpu-baseline --only-extra config5_share_k31 > gpurun_out/c5_$t.json 2> gpurun_out/c5_$t.err || { tail -5 gpurun_out/c5_$t.err; exit 1; }
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/c5_$t.json"))
+e=d["config5_share_k31"]
+print("$t", {k:(round(v,1) if isinstance(v,float) else v) for k,v in e.items() if k in ("value","ms_total","cold_ms","verified","table_slab_bytes","unique","error")})
+PY
+done

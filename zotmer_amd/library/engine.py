@@ -102,13 +102,20 @@ class Slab:
         room = free + (0 if live else 12 * self.E)
         if 12 * want + (1 << 30) > room:                      # the comfortable size does not fit: take exactly what is needed
             want = int(need)
-            if live and spare is not None and spare.E and 12 * want + (1 << 30) > room:
-                spare.release()                               # ... and the scratch slab's memory with it (it regrows at the next merge)
         with _Phase(ctx, "table memory -> %d entries" % want):
             if not live:
                 self.k = self.c = None
                 self.E = 0
-            nk, nc = ctx.empty(want, np.uint64), ctx.empty(want, np.uint32)
+            try:
+                nk, nc = ctx.empty(want, np.uint64), ctx.empty(want, np.uint32)
+            except native.ZotkError:
+                # old pair + new pair + a scratch slab that a swap left at the table's full size do not fit together: the scratch slab
+                # goes first (it regrows at the next merge -- at 34 ms per GB, so only when there is no other way)
+                if not (live and spare is not None and spare.E):
+                    raise
+                nk = nc = None
+                spare.release()
+                nk, nc = ctx.empty(want, np.uint64), ctx.empty(want, np.uint32)
             if live:
                 ctx._check(ctx.lib.zk_copy(ctx.h, nk.ptr, self.k.ptr, 8 * live))
                 ctx._check(ctx.lib.zk_copy(ctx.h, nc.ptr, self.c.ptr, 4 * live))
@@ -260,10 +267,15 @@ class KmerTable:
         # slab is (or the next batch would have to grow it, with a copy); if memory does not allow that, copy back as above
         # the bottom.
         swap = oa == 0
-        if swap and scratch.E < slab.E:
+        # ... as large as the table will have to be, that is: what the input still to come can add at the yield seen so far (when the
+        # caller has said how much is coming), never more than the table slab is now -- a slab that an earlier run left larger than
+        # this run needs (the strands of the last result were rebuilt in it) is not a size to grow the other one to: 34 ms per GB
+        tgt = self._slab_target(n_out)
+        want_E = slab.E if tgt is None else min(slab.E, max(tgt, n_out))
+        if swap and scratch.E < want_E:
             free, _ = ctx.mem_info()
-            if 12 * slab.E + (2 << 30) < free + 12 * scratch.E:          # (growing frees the old scratch first: nothing in it is live)
-                scratch.ensure(slab.E)
+            if 12 * want_E + (2 << 30) < free + 12 * scratch.E:          # (growing frees the old scratch first: nothing in it is live)
+                scratch.ensure(want_E)
             else:
                 swap = False
         scratch.ensure(n_out)
