@@ -337,6 +337,60 @@ def extra_config5_share(ctx, scale, synth, seed, batches=4):
                          "unit": "GB/s"}}
 
 
+def extra_uniform_reads(ctx, sc, synth, seed, cfg, K, L):
+    """SURVEY 8(d)'s secondary workload, "worst case U ~ I": iid bases, no k-mer occurs twice -- the look before the sort declines the
+    top-bits-first plan.  Two figures: 20 M reads as ONE batch of zk_kmerize, and 40 M reads the way `zot kmerize` counts an input
+    that does not fit one batch -- library/engine.py KmerTable: batches counted as canonical lists, union-summed pairwise, the strands
+    rebuilt once.  (50 M such reads do not fit ONE card in any order of work: their table alone is 12.6 G entries = 151 GB, and the
+    strands are rebuilt from a 75 GB canonical list through two 50 GB word buffers: 277 GB + the sort arena; 40 M reads: 221 GB.)"""
+    from zotmer_amd.library import engine
+    Ru = int(20_000_000 * sc)
+    uni = ctx.synth_reads(seed + 1, 0, Ru, L, genome=0, sub_thr=0, n_thr=synth.frac32(cfg["n"]))
+    out = extra_kmerize_variant(
+        ctx, "uniform", uni, K, 2, "SURVEY 8(d) uniform workload: zot kmerize k=%d on %d x %d bp reads of iid bases (no k-mer occurs twice), "
+        "one batch" % (K, Ru, L), 2 * Ru * (L - K + 1) + 1024)
+    del uni
+    ctx.release_workspace()
+    R50, batches = int(40_000_000 * sc), 4
+    per = -(-R50 // batches)
+    runs, want0 = [], None
+    for attempt in range(2):
+        table = engine.KmerTable(ctx, K)
+        table.expect(R50 * (L + 1))
+        want, t_total = (0, 0, 0), 0.0
+        for b in range(batches):
+            n = min(per, R50 - b * per)
+            if n <= 0:
+                break
+            d = ctx.synth_reads(seed + 1, b * per, n, L, genome=0, sub_thr=0, n_thr=synth.frac32(cfg["n"]))
+            if attempt == 0:
+                want = add_sums(want, ctx.stream_checksum(d, K))
+            ctx.sync()
+            t0 = time.perf_counter()
+            table.add_device_stream(d)
+            ctx.sync()
+            t_total += time.perf_counter() - t0
+            del d
+        t0 = time.perf_counter()
+        k, c, h = table.device_result()
+        ctx.sync()
+        t_total += time.perf_counter() - t0
+        runs.append(t_total)
+        if attempt == 0:
+            want0 = want
+    inst = table.instances
+    ok = ctx.checksum(k, c) == want0 and inst == want0[0] and ctx.first_descent(k) == k.n
+    out["reads_40M_in_batches"] = {
+        "workload": "%d x %d bp reads of iid bases in %d batches through library/engine.py KmerTable (canonical lists, pairwise union-sum, strands "
+                    "rebuilt once), hist included" % (R50, L, batches),
+        "value": inst / runs[1] / 1e9, "unit": "Gk-mers/s", "ms_total": runs[1] * 1e3, "cold_ms": runs[0] * 1e3, "instances": inst, "unique": k.n,
+        "verified": bool(ok)}
+    del k, c, table
+    engine.release_table_memory(ctx)
+    ctx.release_workspace()
+    return out
+
+
 def extra_e2e_h2d(ctx, stream, K, steps, out_k, out_c):
     """config 2 with the base stream starting in PINNED HOST memory -- the H2D copy is inside the timed
     region (sequential: the sort needs the whole batch), the result stays in HBM."""
@@ -500,7 +554,8 @@ def main():
     if a.only_extra:
         fn = {"config3_dist": lambda: extra_config3(ctx, 5, a.extras_scale),
               "config4_merge_share": lambda: extra_config4_share(ctx, 3, a.extras_scale),
-              "config5_share_k31": lambda: extra_config5_share(ctx, a.extras_scale, synth, seed)}[a.only_extra]
+              "config5_share_k31": lambda: extra_config5_share(ctx, a.extras_scale, synth, seed),
+              "uniform_reads": lambda: extra_uniform_reads(ctx, a.extras_scale, synth, seed, cfg, K, L)}[a.only_extra]
         r = fn()
         os.dup2(real_stdout, 1)
         print(json.dumps({a.only_extra: r}), flush=True)
@@ -623,15 +678,7 @@ def main():
             stream = None
             ctx.release_workspace()
             try:
-                # SURVEY 8(d)'s secondary workload, "worst case U ~ I": iid bases, no k-mer repeats -- the look before the sort declines
-                # the top-bits-first plan and every key goes through all six passes.  20 M reads: the table of 50 M such reads
-                # (12.6 G entries) and the sort buffers together exceed the card.
-                Ru = int(20_000_000 * sc)
-                uni = ctx.synth_reads(seed + 1, 0, Ru, L, genome=0, sub_thr=0, n_thr=synth.frac32(cfg["n"]))
-                extras["uniform_reads"] = extra_kmerize_variant(
-                    ctx, "uniform", uni, K, 2, "SURVEY 8(d) uniform workload: zot kmerize k=%d on %d x %d bp reads of iid bases (no k-mer occurs twice): "
-                    "the plain six-pass plan" % (K, Ru, L), 2 * Ru * (L - K + 1) + 1024)
-                del uni
+                extras["uniform_reads"] = extra_uniform_reads(ctx, sc, synth, seed, cfg, K, L)
             except Exception as e:
                 extras["uniform_reads"] = {"error": repr(e)}
             ctx.release_workspace()

@@ -148,6 +148,9 @@ struct StreamTags { bool written = false; u64* cuts = nullptr; uint32_t blocks =
 struct StreamSrc { const u8* stream; uint64_t n_bytes; int K; int mode; int lo_bit; int hi_bit = 0; StreamSample* sample = nullptr;
                    StreamTags* tags = nullptr; };   // mode: ZK_KEYS_*; sort bits [lo_bit, hi_bit) (hi_bit 0 = 2K)
 int sort_rbits(zk_ctx* c);
+PassPlan sort_plan_upper(zk_ctx* c, int key_bits, int lo_bit);   // the digits sort_keys_upper(_counted) takes for the bits [lo_bit, key_bits)
+// digit counts of the passes to come, taken by the kernel that writes the words they will sort (no histogram pass of its own then)
+struct MirrorHist { int passes; int shift[4]; int bits[4]; u64* raw; };          // raw: [MAX_PASSES][512], += by the producer
 int sort_first_bits(zk_ctx* c, int key_bits, int lo_bit);
 struct DedupeResult {
     uint64_t n_out = 0;          // distinct keys

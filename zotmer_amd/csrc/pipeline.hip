@@ -34,13 +34,13 @@ __global__ void mirror_kernel(const u64* __restrict__ c, const u32* __restrict__
 constexpr int MIRROR_GROUP_BITS = 18;      // 9 bases: 2^18 groups, tables of 4 MB
 constexpr int MIRROR_GROUP_BASES = MIRROR_GROUP_BITS / 2;
 
-// start[g] = first index whose top MIRROR_GROUP_BITS bits are >= g (g = 2^18: n)
-__global__ void mirror_bounds_kernel(const u64* __restrict__ c, u64 n, int K, u64* __restrict__ start) {
+// start[g] = first index whose top gbits bits are >= g (g = 2^gbits: n)
+__global__ void mirror_bounds_kernel(const u64* __restrict__ c, u64 n, int K, int gbits, u64* __restrict__ start) {
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g > (1u << MIRROR_GROUP_BITS)) return;
-    const u64 want = (u64)g << (2 * K - MIRROR_GROUP_BITS);
+    if (g > (1u << gbits)) return;
+    const u64 want = (u64)g << (2 * K - gbits);
     u64 lo = 0, hi = n;
-    if (g == (1u << MIRROR_GROUP_BITS)) lo = n;
+    if (g == (1u << gbits)) lo = n;
     while (lo < hi) {
         const u64 mid = (lo + hi) >> 1;
         if (c[mid] < want) lo = mid + 1; else hi = mid;
@@ -48,40 +48,34 @@ __global__ void mirror_bounds_kernel(const u64* __restrict__ c, u64 n, int K, u6
     start[g] = lo;
 }
 
-// size_v[v] = size of the group whose mirrored keys end in v, i.e. group g = rc9(v)
-__global__ void mirror_sizes_kernel(const u64* __restrict__ start, u64* __restrict__ size_v) {
+// size_v[v] = size of the group whose mirrored keys end in v, i.e. group g = rc(v) (gbits / 2 bases)
+__global__ void mirror_sizes_kernel(const u64* __restrict__ start, int gbits, u64* __restrict__ size_v) {
     const u32 v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= (1u << MIRROR_GROUP_BITS)) return;
-    const u32 g = (u32)revcomp(MIRROR_GROUP_BASES, (u64)v);
+    if (v >= (1u << gbits)) return;
+    const u32 g = (u32)revcomp(gbits / 2, (u64)v);
     size_v[v] = start[g + 1] - start[g];
 }
 
-// exclusive scan of size_v in place (one workgroup of 1024 threads, 256 consecutive entries each)
-__global__ __launch_bounds__(1024) void mirror_scan_kernel(u64* __restrict__ size_v) {
-    constexpr int G = 1 << MIRROR_GROUP_BITS, PER = G / 1024;
-    __shared__ u64 wsum[16];
-    const int t = threadIdx.x;
-    u64 local = 0;
-#pragma unroll 16
-    for (int j = 0; j < PER; j++) local += size_v[t * PER + j];
-    const u64 inc = wave_incl_scan_u64(local);
-    if ((t & 63) == 63) wsum[t >> 6] = inc;
-    __syncthreads();
-    u64 off = 0;
-    for (int w = 0; w < (t >> 6); w++) off += wsum[w];
-    u64 run = off + inc - local;
-#pragma unroll 16
-    for (int j = 0; j < PER; j++) {
-        const u64 sz = size_v[t * PER + j];
-        size_v[t * PER + j] = run;
-        run += sz;
-    }
+// place[g] = (where the mirrored words of group g go: the sizes before v = rc(g), inclusive scan minus the group's own) - start[g]:
+// the word of entry i of the list goes to place[g] + i.  Indexed by g, the order the copy walks the list in.
+__global__ void mirror_place_kernel(const u64* __restrict__ start, const u64* __restrict__ incl_v, int gbits, u64* __restrict__ place) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (1u << gbits)) return;
+    const u32 v = (u32)revcomp(gbits / 2, (u64)g);
+    place[g] = incl_v[v] - (start[g + 1] - start[g]) - start[g];
 }
 
-// pack > 0: r[pos] = (rc(c) << pack) | n -- one word per pair (v is not written); the caller has checked that every n fits
-__global__ void mirror_copy_kernel(const u64* __restrict__ c, const u32* __restrict__ n, u64 m, int K, const u64* __restrict__ start,
-                                   const u64* __restrict__ dest, u64* __restrict__ r, u32* __restrict__ v, int pack) {
-    const int sh = 2 * K - MIRROR_GROUP_BITS;
+// pack > 0: r[pos] = (rc(c) << pack) | n -- one word per pair (v is not written); the caller has checked that every n fits.
+// mh: the digit counts of the passes that will sort the words above their group bits, taken on the way (it writes every word anyway).
+__global__ __launch_bounds__(256) void mirror_copy_kernel(const u64* __restrict__ c, const u32* __restrict__ n, u64 m, int K, int gbits,
+                                                          const u64* __restrict__ place, u64* __restrict__ r, u32* __restrict__ v, int pack, MirrorHist mh) {
+    __shared__ u32 bins[4 * 512];
+    const bool hist = pack && mh.passes > 0;
+    if (hist) {
+        for (int q = threadIdx.x; q < 4 * 512; q += blockDim.x) bins[q] = 0;
+        __syncthreads();
+    }
+    const int sh = 2 * K - gbits;
     // four entries of a thread in flight at a time
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x; i0 < m; i0 += 4 * stride) {
@@ -98,11 +92,22 @@ __global__ void mirror_copy_kernel(const u64* __restrict__ c, const u32* __restr
             const u64 i = i0 + q * stride;
             if (i >= m) break;
             const u64 x = x4[q];
-            const u32 g = (u32)(x >> sh);
-            const u64 pos = dest[(u32)revcomp(MIRROR_GROUP_BASES, (u64)g)] + (i - start[g]);      // dest is indexed by v = rc9(g)
-            if (pack) r[pos] = (revcomp(K, x) << pack) | (u64)n4[q];
-            else { r[pos] = revcomp(K, x); v[pos] = n4[q]; }
+            const u64 pos = place[(u32)(x >> sh)] + i;
+            if (pack) {
+                const u64 mw = (revcomp(K, x) << pack) | (u64)n4[q];
+                r[pos] = mw;
+                if (hist) {
+#pragma unroll
+                    for (int p = 0; p < 4; p++)
+                        if (p < mh.passes) atomicAdd(&bins[p * 512 + ((u32)(mw >> mh.shift[p]) & ((1u << mh.bits[p]) - 1u))], 1u);
+                }
+            } else { r[pos] = revcomp(K, x); v[pos] = n4[q]; }
         }
+    }
+    if (hist) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < mh.passes * 512; q += blockDim.x)
+            if (bins[q]) atomicAdd(&mh.raw[q], (u64)bins[q]);
     }
 }
 
@@ -180,18 +185,37 @@ static int mirror_union(zk_ctx* c, const u64* sorted, const u32* cnt, uint64_t u
         // an LSD sort of the mirrored keys would only move these 2^18 groups around whole; one copy does it: group
         // boundaries by binary search, group order = order of the reversed-complemented prefix, then only the bits
         // above 18 are sorted.
-        u64 *start, *dest;
-        ZK_TRY(arena_alloc(c, sizeof(u64) * ((1u << MIRROR_GROUP_BITS) + 1), (void**)&start));
-        ZK_TRY(arena_alloc(c, sizeof(u64) * (1u << MIRROR_GROUP_BITS), (void**)&dest));
-        prof_begin(c, ZK_PROF_MIRROR, 24 * uc);
-        hipLaunchKernelGGL(mirror_bounds_kernel, dim3(((1u << MIRROR_GROUP_BITS) + 256) / 256), dim3(256), 0, c->stream, sorted, (u64)uc, K, start);
-        hipLaunchKernelGGL(mirror_sizes_kernel, dim3((1u << MIRROR_GROUP_BITS) / 256), dim3(256), 0, c->stream, start, dest);
-        hipLaunchKernelGGL(mirror_scan_kernel, dim3(1), dim3(1024), 0, c->stream, dest);
-        hipLaunchKernelGGL(mirror_copy_kernel, dim3(ew_grid(c, uc)), dim3(256), 0, c->stream, sorted, cnt, (u64)uc, K, start, dest, rk, rv, pack);
+        // As single words, and when the list is long enough for the tables to be small beside it: grouped by the first TWELVE bases
+        // (2^24 groups; their bounds are 2^24 binary searches) -- one pass less over the words.
+        int gbits = MIRROR_GROUP_BITS;
+        if (pack && 2 * K - 24 >= 8 && uc >= (1ull << 26) && c->arena_size - c->arena_off > 3 * (8ull << 24) + (64ull << 20) + uc / 16) gbits = 24;
+        const u32 groups = 1u << gbits;
+        u64 *start, *incl, *place;
+        ZK_TRY(arena_alloc(c, sizeof(u64) * ((uint64_t)groups + 1), (void**)&start));
+        ZK_TRY(arena_alloc(c, sizeof(u64) * groups, (void**)&incl));
+        ZK_TRY(arena_alloc(c, sizeof(u64) * groups, (void**)&place));
+        // the digit counts of the passes that will sort the words above their group bits: taken by the copy (sort_keys_upper_counted)
+        MirrorHist mh = {};
+        if (pack && c->sort_variant == 3) {
+            const PassPlan plan = sort_plan_upper(c, 2 * K + pack, gbits + pack);
+            if (plan.passes <= 4 && sort_rbits(c) == 9) {
+                ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * 512, (void**)&mh.raw));
+                ZK_HIP(c, hipMemsetAsync(mh.raw, 0, sizeof(u64) * MAX_PASSES * 512, c->stream));
+                mh.passes = plan.passes;
+                for (int p = 0; p < plan.passes; p++) { mh.shift[p] = plan.shift[p]; mh.bits[p] = plan.bits[p]; }
+            }
+        }
+        prof_begin(c, ZK_PROF_MIRROR, (pack ? 20 : 24) * uc);
+        hipLaunchKernelGGL(mirror_bounds_kernel, dim3((groups + 256) / 256), dim3(256), 0, c->stream, sorted, (u64)uc, K, gbits, start);
+        hipLaunchKernelGGL(mirror_sizes_kernel, dim3(groups / 256), dim3(256), 0, c->stream, (const u64*)start, gbits, incl);
+        ZK_TRY(scan64_inclusive(c, incl, groups));
+        hipLaunchKernelGGL(mirror_place_kernel, dim3(groups / 256), dim3(256), 0, c->stream, (const u64*)start, (const u64*)incl, gbits, place);
+        hipLaunchKernelGGL(mirror_copy_kernel, dim3(ew_grid(c, uc)), dim3(256), 0, c->stream, sorted, cnt, (u64)uc, K, gbits, (const u64*)place, rk, rv, pack, mh);
         prof_end(c);
         ZK_HIP(c, hipGetLastError());
         if (pack) {
-            ZK_TRY(sort_keys_upper(c, rk, rk2, uc, 2 * K + pack, MIRROR_GROUP_BITS + pack, &sk));
+            if (mh.passes) ZK_TRY(sort_keys_upper_counted(c, rk, rk2, uc, 2 * K + pack, gbits + pack, mh.raw, &sk));
+            else ZK_TRY(sort_keys_upper(c, rk, rk2, uc, 2 * K + pack, gbits + pack, &sk));
             return union_sum_packed_b(c, sorted, cnt, uc, sk, uc, pack, out_k, out_c, cap, n_out);
         }
         ZK_TRY(sort_pairs_upper(c, rk, rk2, rv, rv2, uc, 2 * K, MIRROR_GROUP_BITS, &sk, &sv));
@@ -209,17 +233,21 @@ int mirror_expand(zk_ctx* c, const u64* ck, const u32* cc, uint64_t n, int K, u6
     if (n == 0) return ZK_OK;
     arena_reset(c);
     const uint64_t a8 = (8 * n + 255) & ~255ull, a4 = (4 * n + 255) & ~255ull;
-    const uint64_t need = 2 * a8 + 2 * a4 + (9 << 20) + n / 8;          // work buffers, group tables, histograms, merge-path partition
-    ZK_TRY(arena_require(c, need, need));
-    char* w;
-    ZK_TRY(arena_alloc(c, 2 * a8 + 2 * a4, (void**)&w));
     int pack = 0;
     if (c->packed_pairs && pack_bits_for(K)) {
         uint64_t mx = 0;
         ZK_TRY(max_u32(c, cc, n, &mx));
         if (mx < (1ull << pack_bits_for(K))) pack = pack_bits_for(K);
     }
-    ZK_TRY(mirror_union(c, ck, cc, n, K, (u64*)w, (u64*)(w + a8), (u32*)(w + 2 * a8), (u32*)(w + 2 * a8 + a4), out_k, out_c, cap, n_out, pack));
+    // the mirrored pairs as single words (every count fits beside its k-mer): two word buffers, 16 bytes an entry; as pairs: 24
+    const bool words = pack && 2 * K >= MIRROR_GROUP_BITS + 8 && n >= (1ull << 16);
+    const uint64_t wbytes = 2 * a8 + (words ? 0 : 2 * a4);
+    const uint64_t need = wbytes + (9 << 20) + n / 8 + (words && n >= (1ull << 26) ? (480ull << 20) : 0);          // work buffers, group tables (2^24 groups of long lists), histograms, merge-path partition
+    ZK_TRY(arena_require(c, need, need));
+    char* w;
+    ZK_TRY(arena_alloc(c, wbytes, (void**)&w));
+    ZK_TRY(mirror_union(c, ck, cc, n, K, (u64*)w, (u64*)(w + a8), words ? nullptr : (u32*)(w + 2 * a8), words ? nullptr : (u32*)(w + 2 * a8 + a4), out_k, out_c,
+                        cap, n_out, pack));
     return check_device_error(c);
 }
 
@@ -544,8 +572,9 @@ int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, dou
     const uint64_t cap_keys = both ? 2 * n_bytes : n_bytes;   // one window per stream byte at most
     arena_reset(c);
     // histograms, merge-path partitions, the mirror group tables (4 MB); from 2^29 stream bytes on (block dedupe with 2^18 blocks) the
-    // blocks' tables as well: bounds, sizes, and the 2^24 run places of the mirror grouping (336 MB)
-    const uint64_t slack = (16 << 20) + cap_keys / 16 + ((n_bytes >= (1ull << 29) || c->dedupe_bits >= 18) ? (384ull << 20) : 0);          // (+ the block starts of the tag path: 2 MB; the list of declined blocks: 1 MB)
+    // blocks' tables as well: bounds, sizes, and the 2^24 run places of the mirror grouping (336 MB) -- or, where the blocks were not
+    // counted that way, the 2^24 group bounds, ends and places of mirror_union (403 MB)
+    const uint64_t slack = (16 << 20) + cap_keys / 16 + ((n_bytes >= (1ull << 29) || c->dedupe_bits >= 18) ? (832ull << 20) : 0);          // (+ the block starts of the tag path: 2 MB; the list of declined blocks: 1 MB)
     ZK_TRY(arena_require(c, 16 * cap_keys + slack, 16 * cap_keys + slack));
     u64 *buf_a, *buf_b;
     ZK_TRY(arena_alloc(c, 8 * cap_keys, (void**)&buf_a));

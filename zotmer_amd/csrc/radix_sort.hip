@@ -1229,7 +1229,6 @@ __global__ __launch_bounds__(1024, 4) void dedupe_kernel(DedupeArgs a) {
 // out_m (or null): beside them the mirrored words (rc(key) << pack | count), already grouped by their low block bits -- block v of
 // the list IS group rc(v) of the mirror list (the first bases of a k-mer are the last of its reverse complement), and minc holds
 // the groups' inclusive ends: the first stage of the mirror sort comes for free with the copy that is made anyway.
-struct MirrorHist { int passes; int shift[4]; int bits[4]; u64* raw; };          // raw: [passes][512] digit counts of the mirrored words, += here
 
 __global__ __launch_bounds__(256) void dedupe_unpack_kernel(const u64* __restrict__ in, const u64* __restrict__ cuts, const u64* __restrict__ incl,
                                                             const u64* __restrict__ nwords, u32 chunks, int pack, u64* __restrict__ out_k,
@@ -2153,6 +2152,9 @@ int sort_pairs_mirrored(zk_ctx* c, const u64* src_k, const u32* src_v, u64* keys
 }
 
 // digit width of the geometry used for key arrays (the truncated sort sizes its bit range with it)
+// the digits sort_keys_upper / sort_keys_upper_counted will use for the bits [lo_bit, key_bits)
+PassPlan sort_plan_upper(zk_ctx* c, int key_bits, int lo_bit) { return make_plan(key_bits - lo_bit, sort_rbits(c), lo_bit); }
+
 int sort_rbits(zk_ctx* c) {
     switch (c->sort_variant) { case 0: case 1: case 5: return 8; default: return 9; }
 }
