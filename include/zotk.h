@@ -262,6 +262,13 @@ int zk_comm_info(zk_ctx* ctx, int* world, int* rank);          /* 1, 0 without a
  * mesh, straight between the callers' arrays, <= 256 MiB per message and round; asynchronous on the ctx's stream. */
 int zk_all_to_all_v(zk_ctx* ctx, const void* d_send, const uint64_t* send_off, const uint64_t* send_cnt, void* d_recv,
                     const uint64_t* recv_off, const uint64_t* recv_cnt, int elem_bytes);
+/* The messages zk_all_to_all_v issues, as data (host only; no GPU, no RCCL needed): rank `rank` of `world`, same arguments; chunk_bytes 0 =
+ * 256 MiB; self_loop as ZK_TUNE_COMM_SELF_LOOP.  ops[0 .. min(*n_ops, cap)) in issue order: recv 0 = a send of bytes [offset, offset + bytes)
+ * of d_send to `peer`, 1 = a receive into those bytes of d_recv from `peer`; all the ops of one `round` form one ncclGroup.  For tests: what
+ * a box with one GPU cannot execute -- the pairing of the ranks and the offsets of their pieces -- is checked on the CPU. */
+typedef struct { int32_t recv; int32_t peer; uint64_t round; uint64_t offset; uint64_t bytes; } zk_comm_op;
+int zk_comm_plan(int world, int rank, const uint64_t* send_off, const uint64_t* send_cnt, const uint64_t* recv_off, const uint64_t* recv_cnt,
+                 int elem_bytes, uint64_t chunk_bytes, int self_loop, zk_comm_op* ops, uint64_t cap, uint64_t* n_ops);
 /* in-place all-reduce of n HOST values (dist's (a, b, c), checksums, the splitter histogram); synchronises */
 int zk_allreduce_u64(zk_ctx* ctx, uint64_t* vals, uint64_t n, int op);
 

@@ -15,6 +15,8 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <vector>
+
 #include <rccl/rccl.h>
 
 #include "internal.hpp"
@@ -59,11 +61,46 @@ static Rccl* rccl() {
             return zk::fail((c), ZK_EHIP, "%s failed: %s (%s:%d)", #call, rccl()->GetErrorString(r__), __FILE__, __LINE__); \
     } while (0)
 
+// The schedule of zk_all_to_all_v, as data: the messages rank `me` of `world` puts into round j, in the order it issues them.
+// A pure function of the counts (no GPU, no RCCL), so that the part of the exchange a box with one GPU cannot run -- who talks to
+// whom in which round, at which byte offsets -- is checked on the CPU for every world size (tests/test_comm_plan.py): over all
+// ranks every send has exactly one receive of the same length in the same round, and the pieces are covered once.
+static void a2a_plan(int world, int me, const uint64_t* send_off, const uint64_t* send_cnt, const uint64_t* recv_off, const uint64_t* recv_cnt,
+                     uint64_t eb, uint64_t chunk, bool self_loop, std::vector<zk_comm_op>* ops, uint64_t* rounds_out) {
+    uint64_t biggest = 0;
+    for (int p = 0; p < world; p++) {
+        if (p == me && !self_loop) continue;
+        if (send_cnt[p] * eb > biggest) biggest = send_cnt[p] * eb;
+        if (recv_cnt[p] * eb > biggest) biggest = recv_cnt[p] * eb;
+    }
+    const uint64_t rounds = (biggest + chunk - 1) / chunk;
+    for (uint64_t j = 0; j < rounds; j++) {
+        for (int d = self_loop ? 0 : 1; d < world; d++) {
+            // talk to (me + d) and (me - d) in the same step, so that every link is busy in both directions
+            const int to = (me + d) % world, from = (me - d + world) % world;
+            const uint64_t sb = send_cnt[to] * eb, rb = recv_cnt[from] * eb;
+            if (j * chunk < sb) ops->push_back(zk_comm_op{0, to, j, send_off[to] * eb + j * chunk, sb - j * chunk < chunk ? sb - j * chunk : chunk});
+            if (j * chunk < rb) ops->push_back(zk_comm_op{1, from, j, recv_off[from] * eb + j * chunk, rb - j * chunk < chunk ? rb - j * chunk : chunk});
+        }
+    }
+    if (rounds_out) *rounds_out = rounds;
+}
+
 }  // namespace zk
 
 using namespace zk;
 
 extern "C" {
+
+int zk_comm_plan(int world, int rank, const uint64_t* send_off, const uint64_t* send_cnt, const uint64_t* recv_off, const uint64_t* recv_cnt,
+                 int elem_bytes, uint64_t chunk_bytes, int self_loop, zk_comm_op* ops, uint64_t cap, uint64_t* n_ops) {
+    if (world < 1 || rank < 0 || rank >= world || !send_off || !send_cnt || !recv_off || !recv_cnt || elem_bytes < 1 || !n_ops) return ZK_EINVAL;
+    std::vector<zk_comm_op> v;
+    a2a_plan(world, rank, send_off, send_cnt, recv_off, recv_cnt, (uint64_t)elem_bytes, chunk_bytes ? chunk_bytes : (256ull << 20), self_loop != 0, &v, nullptr);
+    *n_ops = v.size();
+    if (ops) for (uint64_t i = 0; i < v.size() && i < cap; i++) ops[i] = v[i];
+    return ZK_OK;
+}
 
 int zk_comm_unique_id(uint8_t id[ZK_COMM_ID_BYTES]) {
     Rccl* r = rccl();
@@ -126,27 +163,16 @@ int zk_all_to_all_v(zk_ctx* c, const void* d_send, const uint64_t* send_off, con
                                  hipMemcpyDeviceToDevice, c->stream));
     if (W == 1 && !self_loop) return ZK_OK;
     const uint64_t chunk = c->comm_chunk_bytes ? c->comm_chunk_bytes : (256ull << 20);     // bytes per message and round
-    uint64_t biggest = 0;
-    for (int p = 0; p < W; p++) {
-        if (p == me && !self_loop) continue;
-        if (send_cnt[p] * eb > biggest) biggest = send_cnt[p] * eb;
-        if (recv_cnt[p] * eb > biggest) biggest = recv_cnt[p] * eb;
-    }
-    const uint64_t rounds = div_up(biggest, chunk);
+    std::vector<zk_comm_op> ops;
+    uint64_t rounds = 0;
+    a2a_plan(W, me, send_off, send_cnt, recv_off, recv_cnt, eb, chunk, self_loop, &ops, &rounds);
+    size_t i = 0;
     for (uint64_t j = 0; j < rounds; j++) {
         ZK_NCCL(c, r->GroupStart());
-        for (int d = self_loop ? 0 : 1; d < W; d++) {
-            // talk to (me + d) and (me - d) in the same step, so that every link is busy in both directions
-            const int to = (me + d) % W, from = (me - d + W) % W;
-            const uint64_t sb = send_cnt[to] * eb, rb = recv_cnt[from] * eb;
-            if (j * chunk < sb) {
-                const uint64_t len = sb - j * chunk < chunk ? sb - j * chunk : chunk;
-                ZK_NCCL(c, r->Send((const char*)d_send + send_off[to] * eb + j * chunk, len, ncclUint8, to, (ncclComm_t)c->comm, c->stream));
-            }
-            if (j * chunk < rb) {
-                const uint64_t len = rb - j * chunk < chunk ? rb - j * chunk : chunk;
-                ZK_NCCL(c, r->Recv((char*)d_recv + recv_off[from] * eb + j * chunk, len, ncclUint8, from, (ncclComm_t)c->comm, c->stream));
-            }
+        for (; i < ops.size() && ops[i].round == j; i++) {
+            const zk_comm_op& o = ops[i];
+            if (o.recv) ZK_NCCL(c, r->Recv((char*)d_recv + o.offset, o.bytes, ncclUint8, o.peer, (ncclComm_t)c->comm, c->stream));
+            else ZK_NCCL(c, r->Send((const char*)d_send + o.offset, o.bytes, ncclUint8, o.peer, (ncclComm_t)c->comm, c->stream));
         }
         ZK_NCCL(c, r->GroupEnd());
     }

@@ -115,6 +115,7 @@ SIGNATURES = {
     "zk_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
     "zk_all_to_all_v": (_i, [_vp, _vp, _pu64, _pu64, _vp, _pu64, _pu64, _i]),
     "zk_allreduce_u64": (_i, [_vp, _pu64, _u64, _i]),
+    "zk_comm_plan": (_i, [_i, _i, _pu64, _pu64, _pu64, _pu64, _i, _u64, _i, _vp, _u64, _pu64]),
     "zk_stream_checksum": (_i, [_vp, _vp, _u64, _i, _pu64]),
 }
 
@@ -666,6 +667,22 @@ class Context:
         arr = lambda v: (C.c_uint64 * W)(*[int(x) for x in v])
         self._check(self.lib.zk_all_to_all_v(self.h, send_ptr, arr(send_off), arr(send_cnt), recv_ptr, arr(recv_off), arr(recv_cnt),
                                              int(elem_bytes)))
+
+    @staticmethod
+    def comm_plan(world, rank, send_off, send_cnt, recv_off, recv_cnt, elem_bytes, chunk_bytes=0, self_loop=False):
+        """The messages zk_all_to_all_v issues for this rank, as a list of dicts (host only: no GPU, no RCCL) -- zk_comm_plan."""
+        class Op(C.Structure):
+            _fields_ = [("recv", C.c_int32), ("peer", C.c_int32), ("round", C.c_uint64), ("offset", C.c_uint64), ("bytes", C.c_uint64)]
+        arr = lambda v: (C.c_uint64 * world)(*[int(x) for x in v])
+        a = (arr(send_off), arr(send_cnt), arr(recv_off), arr(recv_cnt))
+        n = C.c_uint64(0)
+        lib = load()
+        rc = lib.zk_comm_plan(world, rank, a[0], a[1], a[2], a[3], int(elem_bytes), int(chunk_bytes), int(bool(self_loop)), None, 0, C.byref(n))
+        if rc != ZK_OK:
+            raise ZotkError(rc, "zk_comm_plan: bad argument")
+        ops = (Op * max(n.value, 1))()
+        lib.zk_comm_plan(world, rank, a[0], a[1], a[2], a[3], int(elem_bytes), int(chunk_bytes), int(bool(self_loop)), ops, n.value, C.byref(n))
+        return [dict(recv=o.recv, peer=o.peer, round=o.round, offset=o.offset, bytes=o.bytes) for o in ops[:n.value]]
 
     def allreduce_u64(self, vals, op=0):
         a = np.ascontiguousarray(vals, dtype=np.uint64).copy()
