@@ -94,6 +94,8 @@ int zk_upload_async(zk_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
                                   * and the second pass is a count / scan / scatter over static segments that writes whole 64-byte units of tags
                                   * (tag_pass.hip); 0 (default) = whole keys and the look-back pipeline.  Same result either way; measured slower
                                   * in all (profiles/r04/tag_pass_ab.json: the second pass gains 5 ms, pass 0 loses 8.5) */
+#define ZK_TUNE_KWAY 18          /* zk_merge_n: 1 (default) = inputs of 4 Mi pairs or more are union-summed up to 16 lists at a time, in one pass over the data
+                                  * (kway.hip); 2 = every input (tests); 0 = always the tree of 2-way passes */
 #define ZK_TUNE_COMM_SELF_LOOP 16 /* tests: 1 = the piece a rank keeps goes through grouped ncclSend / ncclRecv to itself, in the same rounds as
                                   * the other pieces (instead of a device copy), and zk_allreduce_u64 calls ncclAllReduce with one rank too:
                                   * the RCCL data path of zk_comm_* executed on a box with one GPU; 0 (default) */

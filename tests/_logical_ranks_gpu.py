@@ -20,6 +20,25 @@ sys.path.insert(0, ROOT)
 from oracle import zkoracle as zo                 # noqa: E402
 from zotmer_amd import native, parallel, synth    # noqa: E402
 
+# Eight contexts share ONE GPU here, which no product run does (one process and one context per GPU).  The radix-sort pipelines are
+# persistent kernels that take whole CUs (150 KB of LDS a workgroup) and whose scanner workgroups wait for the counts of 32 tiles
+# at a time: eight of them at once can leave every one with too few resident workgroups to finish a batch (measured: 2 of 30 runs
+# of this script hit the bounded spin, also on the round-3 tree).  What this script tests is the exchange logic over 8 ranks, not
+# eight kernels sharing a card, so the library calls of the eight threads are serialised: one context on the GPU at a time.
+_device_lock = threading.Lock()
+
+
+def _serialise_library_calls():
+    lib = native.load()
+    for name in native.SIGNATURES:
+        fn = getattr(lib, name)
+
+        def locked(*a, _fn=fn):
+            with _device_lock:
+                return _fn(*a)
+        setattr(lib, name, locked)
+
+
 W = 8
 SCALE = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0004        # 64 sets x 20 000 keys from a pool of 80 000
 K = 25
@@ -156,6 +175,7 @@ def worker(rank, owner, host_sets, results):
 
 
 def main():
+    _serialise_library_calls()
     host_sets = make_sets()
     zs, zc, zacgt = zo.merge_n(K, host_sets)
     hv, hf = zo.hist(zc)

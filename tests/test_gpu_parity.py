@@ -611,16 +611,35 @@ def test_union_sum_random_vs_oracle(ctx, nx, ny):
 
 
 def test_merge_n_random_vs_oracle(ctx):
+    """zk_merge_n: up to 16 lists per pass (kway.hip: sampled splitters, tiles merged in LDS) and the tree of 2-way passes (kway = 0)
+    against the oracle's mergeNinto -- list counts around the fan-in (16, 17, 40: two levels), empty lists, lists that share most of
+    their keys (long runs of equal keys across lists), a list far longer than the others, tiny inputs (fewer keys than one sample step)."""
     rng = np.random.default_rng(99)
-    for k in (1, 2, 3, 7, 8, 13):
-        sets = []
-        for s in range(k):
-            n = int(rng.integers(0, 40000))
-            x = np.sort(rng.choice(np.arange(1 << 18, dtype=np.uint64) << np.uint64(30), size=n, replace=False))
-            sets.append((x, rng.integers(1, 50, size=n, dtype=np.uint64)))
-        zs, zc, acgt = zo.merge_n(25, sets)
-        gk, gc, gacgt = ctx.merge_n([(ctx.upload(a), ctx.upload(b)) for a, b in sets])
-        assert np.array_equal(gk.to_host(), zs) and np.array_equal(gc.to_host(), zc) and gacgt == acgt
+    try:
+        for k in (1, 2, 3, 7, 8, 13, 16, 17, 40):
+            for shape in ("spread", "shared", "skewed", "tiny"):
+                sets = []
+                pool = np.arange(1 << 18, dtype=np.uint64) << np.uint64(30)
+                if shape == "shared":
+                    pool = pool[:60000]
+                for s in range(k):
+                    n = int(rng.integers(0, 40000))
+                    if shape == "skewed":
+                        n = 200000 if s == 1 else int(rng.integers(0, 300))
+                    if shape == "tiny":
+                        n = int(rng.integers(0, 40))
+                    if s == 2:
+                        n = 0
+                    x = np.sort(rng.choice(pool, size=min(n, len(pool)), replace=False))
+                    sets.append((x, rng.integers(1, 50, size=len(x), dtype=np.uint64)))
+                zs, zc, acgt = zo.merge_n(25, sets)
+                dev = [(ctx.upload(a), ctx.upload(b)) for a, b in sets]
+                for kway in (2, 0):
+                    ctx.tune(kway=kway)
+                    gk, gc, gacgt = ctx.merge_n(dev)
+                    assert np.array_equal(gk.to_host(), zs) and np.array_equal(gc.to_host(), zc) and gacgt == acgt, (k, shape, kway)
+    finally:
+        ctx.tune(kway=1)
 
 
 # ---- K8/K9 dist --------------------------------------------------------------------------------------------------

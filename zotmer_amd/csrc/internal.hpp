@@ -35,6 +35,7 @@ struct zk_ctx {
     int tag_pass = 0;          // ... 1 = the pass that writes them is tag_pass.hip's count / scan / scatter over static segments, reading pass 0's
                                // keys as two arrays (6 bytes a key); 0 (default) = the look-back pipeline over whole keys.  Measured
                                // (profiles/r04/tag_pass_ab.json): the pass 25.0 -> 17.4 + 2.2 ms, but pass 0 21.3 -> 29.8 ms (half-line units)
+    int kway = 1;              // zk_merge_n: 1 = up to 16 lists per pass (kway.hip) from 4 Mi pairs on, 2 = always, 0 = the tree of 2-way passes
     int dedupe_bits = 0;       // tests: > 0 = the block dedupe with this many block bits whatever the input's size (pipeline.hip)
     int stream_ranges = 0;     // ... ranges the stream is cut into (0 = two per CU; tests use a few so that a range has many tiles)
 
@@ -218,6 +219,9 @@ void ring_destroy(zk_ctx* c);
 int hash_partition(zk_ctx* c, const u64* keys, const void* cnts, int count_bits, uint64_t n, int world, u64 seed, u64* ok, void* oc,
                    uint64_t* offsets);
 int checksum_any(zk_ctx* c, const u64* keys, const void* cnts, int count_bits, uint64_t n, uint64_t sums[3]);
+// kway.hip: the union-sum of 2 .. 16 sorted lists in one pass
+int kway_union_sum(zk_ctx* c, int k, const u64* const* keys, const void* const* cnts, const uint64_t* ns, u64* out_k, void* out_c, int count_bits,
+                   uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);
 // setops.hip
 int union_sum(zk_ctx* c, const u64* A, const void* cA, u64 nA, const u64* B, const void* cB, u64 nB, u64* ok, void* oc,
               int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);

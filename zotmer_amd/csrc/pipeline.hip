@@ -619,7 +619,7 @@ int merge_many(zk_ctx* c, int k, const u64* const* keys, const void* const* cnts
     // two ping-pong regions, each able to hold every intermediate list of one level
     const uint64_t slack = 1 << 20;
     const uint64_t rbytes = (8 + cb) * total + 512ull * k;
-    const uint64_t need = 2 * rbytes + total / 8 + total / 32 + 8192ull * k + slack;   // + merge-path partitions, acgt rows
+    const uint64_t need = 2 * rbytes + total / 2 + 8192ull * k + slack;   // + merge-path partitions, acgt rows; the k-way pass: its sample (twice), tile bounds
     ZK_TRY(arena_require(c, need, need));
     struct L { const u64* k; const void* c; uint64_t n; };
     std::vector<L> va(k), vb(k);
@@ -633,38 +633,52 @@ int merge_many(zk_ctx* c, int k, const u64* const* keys, const void* const* cnts
         const char* b = (const char*)q;
         return (b >= region[0] && b < region[0] + rbytes) || (b >= region[1] && b < region[1] + rbytes);
     };
+    // Fan-in of a level: up to 16 lists in ONE pass (kway.hip) -- the eight sets of a GPU in BASELINE config 4 are one level, 64 sets
+    // two -- or pairs (zk_tune ZK_TUNE_KWAY 0: the tree of 2-way passes)
+    // (small inputs keep the tree: the k-way pass sorts a sample with the radix-sort pipeline, eight launches that a few thousand pairs
+    // do not pay for; ZK_TUNE_KWAY 2 takes it always -- the tests)
+    const int F = (c->kway == 2 || (c->kway == 1 && total >= (1ull << 22))) ? 16 : 2;
     int m = k, level = 0;
     while (m > 1) {
-        const bool last = (m == 2);
+        const bool last = (m <= F);
         char* base = region[level & 1];
         uint64_t off = 0;
         int o = 0;
-        for (int i = 0; i + 1 < m; i += 2) {
-            const uint64_t cap2 = cur[i].n + cur[i + 1].n;
+        for (int i = 0; i < m; i += F) {
+            const int g = m - i < F ? m - i : F;          // lists of this group
+            if (g == 1) {
+                // the odd list sits out this level; if it lives in a ping-pong region the level after next would overwrite it, so
+                // move it along with this level's outputs
+                L x = cur[i];
+                if (in_regions(x.k)) {
+                    u64* ok = (u64*)(base + off); off += (8 * x.n + 255) & ~255ull;
+                    void* oc = (void*)(base + off); off += (cb * x.n + 255) & ~255ull;
+                    ZK_HIP(c, hipMemcpyAsync(ok, x.k, 8 * x.n, hipMemcpyDeviceToDevice, c->stream));
+                    ZK_HIP(c, hipMemcpyAsync(oc, x.c, cb * x.n, hipMemcpyDeviceToDevice, c->stream));
+                    x.k = ok; x.c = oc;
+                }
+                nxt[o++] = x;
+                continue;
+            }
+            uint64_t capg = 0;
+            for (int j = 0; j < g; j++) capg += cur[i + j].n;
             u64* ok; void* oc; uint64_t capo;
             if (last) { ok = out_k; oc = out_c; capo = cap; }
             else {
-                ok = (u64*)(base + off); off += (8 * cap2 + 255) & ~255ull;
-                oc = (void*)(base + off); off += (cb * cap2 + 255) & ~255ull;
-                capo = cap2;
+                ok = (u64*)(base + off); off += (8 * capg + 255) & ~255ull;
+                oc = (void*)(base + off); off += (cb * capg + 255) & ~255ull;
+                capo = capg;
             }
             uint64_t no = 0;
-            ZK_TRY(union_sum(c, cur[i].k, cur[i].c, cur[i].n, cur[i + 1].k, cur[i + 1].c, cur[i + 1].n, ok, oc, count_bits, capo, &no,
-                             last ? acgt_w : nullptr));
-            nxt[o++] = L{ok, oc, no};
-        }
-        if (m & 1) {
-            // the odd list sits out this level; if it lives in a ping-pong region the level after
-            // next would overwrite it, so move it along with this level's outputs
-            L x = cur[m - 1];
-            if (in_regions(x.k)) {
-                u64* ok = (u64*)(base + off); off += (8 * x.n + 255) & ~255ull;
-                void* oc = (void*)(base + off); off += (cb * x.n + 255) & ~255ull;
-                ZK_HIP(c, hipMemcpyAsync(ok, x.k, 8 * x.n, hipMemcpyDeviceToDevice, c->stream));
-                ZK_HIP(c, hipMemcpyAsync(oc, x.c, cb * x.n, hipMemcpyDeviceToDevice, c->stream));
-                x.k = ok; x.c = oc;
+            if (g == 2) {
+                ZK_TRY(union_sum(c, cur[i].k, cur[i].c, cur[i].n, cur[i + 1].k, cur[i + 1].c, cur[i + 1].n, ok, oc, count_bits, capo, &no,
+                                 last ? acgt_w : nullptr));
+            } else {
+                const u64* gk[16]; const void* gc[16]; uint64_t gn[16];
+                for (int j = 0; j < g; j++) { gk[j] = cur[i + j].k; gc[j] = cur[i + j].c; gn[j] = cur[i + j].n; }
+                ZK_TRY(kway_union_sum(c, g, gk, gc, gn, ok, oc, count_bits, capo, &no, last ? acgt_w : nullptr));
             }
-            nxt[o++] = x;
+            nxt[o++] = L{ok, oc, no};
         }
         L* t = cur; cur = nxt; nxt = t;
         m = o;

@@ -320,7 +320,9 @@ class Context:
 
     def tune(self, sort_variant=None, pairs_variant=None, short_sort=None, side_div=None, xcd_group=None, comm_chunk=None,
              early_collapse=None, packed_pairs=None, wide_tiles=None, stream_pass=None, stream_ranges=None, tag_words=None,
-             dedupe_variant=None, dedupe_limit=None, dedupe_bits=None, comm_self_loop=None, tag_pass=None):
+             dedupe_variant=None, dedupe_limit=None, dedupe_bits=None, comm_self_loop=None, tag_pass=None, kway=None):
+        if kway is not None:
+            self._check(self.lib.zk_tune(self.h, 18, int(kway)))
         if tag_pass is not None:
             self._check(self.lib.zk_tune(self.h, 17, int(tag_pass)))
         if comm_self_loop is not None:
