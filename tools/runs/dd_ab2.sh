@@ -3,7 +3,7 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -k "forced_block_dedupe or large_properties" > gpurun_out/t_dd.log 2>&1 || { tail -30 gpurun_out/t_dd.log; exit 1; }
 tail -3 gpurun_out/t_dd.log
-for v in 0 1 2; do
+for v in 0; do
   ZOT_TUNE=dedupe_variant=$v timeout -k 10 200 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/b_dd$v.json 2> gpurun_out/b_dd$v.err || { tail -5 gpurun_out/b_dd$v.err; exit 1; }
   python - <<PY
 import json

@@ -319,7 +319,6 @@ int zk_tune(zk_ctx* c, int what, int value) {
     if (what == ZK_TUNE_PACKED_PAIRS) { c->packed_pairs = value ? 1 : 0; return ZK_OK; }
     if (what == ZK_TUNE_EARLY_COLLAPSE) { c->early_collapse = value < 0 ? 0 : (value > 3 ? 3 : value); return ZK_OK; }
     if (what == ZK_TUNE_COMM_SELF_LOOP) { c->comm_self_loop = value ? 1 : 0; return ZK_OK; }
-    if (what == ZK_TUNE_COMM_SELF_LOOP) { c->comm_self_loop = value ? 1 : 0; return ZK_OK; }
     if (what == ZK_TUNE_COMM_CHUNK) { c->comm_chunk_bytes = value > 0 ? (uint64_t)value : 0; return ZK_OK; }
     if (what == ZK_TUNE_STREAM_PASS) {
 #ifdef ZK_PHASES

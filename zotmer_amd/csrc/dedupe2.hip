@@ -125,7 +125,7 @@ __device__ __forceinline__ void dedupe2_block(const DedupeArgs& a, Dedupe2Smem<B
         // leaves the word as it is; no other key is ever sent there
         u32 hh = __umulhi(e * 0x9E3779B1u, HS);
         asm("" : "+v"(hh));          // (opaque: left to itself the compiler branches around the two multiplies for the one tag that does not need them)
-        return e == EMPTY ? HS : hh;
+        return e == EMPTY ? HS : hh;          // (24-bit multiplies instead -- fold, multiply, scale: six full-rate operations -- no faster: 12.4 ms)
     };
     auto count = [&](u32 h, u32 inc) { atomicAdd(&sm.cnt[h >> 1], inc << ((h & 1u) << 4)); };
     // up to 64 entries of the wave's side list into the table by linear probing
@@ -199,8 +199,7 @@ __device__ __forceinline__ void dedupe2_block(const DedupeArgs& a, Dedupe2Smem<B
     // thread t takes the entries t, t + BLOCK, ... into registers with their places in their groups (a returning add); the table's
     // memory then takes them back grouped.  (256 groups of a dozen entries: the rank loop runs as long as the largest group of a
     // wavefront, one LDS round trip per turn -- 16 K of a block's 58 K cycles.)
-    sm.g.bc[tid] = 0; sm.g.bc[tid + BLOCK] = 0;          // the side lists are done with: every wave has passed the barrier above
-    static_assert(NB == 2 * BLOCK, "two counters a thread");
+    for (int q = tid; q < NB; q += BLOCK) sm.g.bc[q] = 0;          // the side lists are done with: every wave has passed the barrier above
     u32 et[SPT], ec[SPT];          // ec: count | place in the group << 16
     const int gb = a.tag_bits < 10 ? a.tag_bits : 10, bsh = a.tag_bits - gb;
     const u16* cnt16 = reinterpret_cast<const u16*>(sm.cnt);
@@ -246,26 +245,53 @@ __device__ __forceinline__ void dedupe2_block(const DedupeArgs& a, Dedupe2Smem<B
     next_block(nchunk);          // the next block's first tile travels while this one is ranked and written (asked for any earlier, its
                                  // registers are held beside the entries above: 20 spilled)
     const u64 hi_part = (u64)chunk << a.tag_bits;          // the bits every key of the block has above its tag
-    for (u32 i = (u32)tid; i < total; i += BLOCK) {
-        const u32 mine = sm.keys[i];
-        const u32 b = (mine >> bsh) & (NB - 1);
-        const u32 g0 = sm.g.bbase[b], g1 = sm.g.bbase[b + 1];
-        u32 rank = 0;
-        for (u32 q = g0; q < g1; q += 4) {          // four of the group at a time: one round trip for most groups
-            u32 o[4];
+    // three entries of a thread at a time: their LDS round trips (entry, group bounds, the group's first four tags) overlap -- one entry
+    // after the other this loop was a chain of five round trips per entry, 11 K of a block's 52 K cycles
+    constexpr int E = 3;
+    for (u32 i0 = (u32)tid; i0 < total; i0 += E * BLOCK) {
+        u32 mine[E], cc[E], g0[E], g1[E], rank[E];
 #pragma unroll
-            for (int r = 0; r < 4; r++) o[r] = sm.keys[q + r < (u32)ALL ? q + r : (u32)ALL - 1];
+        for (int e = 0; e < E; e++) {
+            const u32 i = i0 + e * BLOCK;
+            mine[e] = sm.keys[i < total ? i : 0u];
+            cc[e] = cnt16[i < total ? i : 0u];
+        }
 #pragma unroll
-            for (int r = 0; r < 4; r++) rank += (q + r < g1 && o[r] < mine) ? 1u : 0u;
+        for (int e = 0; e < E; e++) {
+            const u32 b = (mine[e] >> bsh) & (NB - 1);
+            g0[e] = sm.g.bbase[b]; g1[e] = sm.g.bbase[b + 1];
         }
-        const u32 c = cnt16[i];
-        const u64 k = hi_part | (u64)mine;
-        if (c > maxc) {
-            const u32 at = atomicAdd(a.n_big, 1u);
-            if (at < a.big_cap) { a.big[2 * (u64)at] = k; a.big[2 * (u64)at + 1] = c; }
-            atomicOr(a.flags, 2u);
+        u32 o[E][4];
+#pragma unroll
+        for (int e = 0; e < E; e++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[e][r] = sm.keys[g0[e] + r < (u32)ALL ? g0[e] + r : (u32)ALL - 1];
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            rank[e] = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) rank[e] += (g0[e] + r < g1[e] && o[e][r] < mine[e]) ? 1u : 0u;
+            for (u32 q = g0[e] + 4; q < g1[e]; q += 4) {          // (a group of more than four: rare with 1024 groups of ~3)
+                u32 p4[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) p4[r] = sm.keys[q + r < (u32)ALL ? q + r : (u32)ALL - 1];
+#pragma unroll
+                for (int r = 0; r < 4; r++) rank[e] += (q + r < g1[e] && p4[r] < mine[e]) ? 1u : 0u;
+            }
         }
-        a.out[lo + g0 + rank] = (k << a.pack) | (u64)(c > maxc ? 0u : c);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const u32 i = i0 + e * BLOCK;
+            if (i >= total) break;
+            const u32 c = cc[e];
+            const u64 k = hi_part | (u64)mine[e];
+            if (c > maxc) {
+                const u32 at = atomicAdd(a.n_big, 1u);
+                if (at < a.big_cap) { a.big[2 * (u64)at] = k; a.big[2 * (u64)at + 1] = c; }
+                atomicOr(a.flags, 2u);
+            }
+            a.out[lo + g0[e] + rank[e]] = (k << a.pack) | (u64)(c > maxc ? 0u : c);
+        }
     }
     DD_PHASE(5);          // ranked and written
 }
