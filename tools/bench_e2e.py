@@ -69,6 +69,22 @@ for rep in ("cold", "warm"):
         out["kmerize_%s_%s_s" % (nm, rep)] = t
         if ph:
             out["kmerize_%s_%s_phases_ms" % (nm, rep)] = {k: round(v, 1) for k, v in ph.items()}
+if "--io-sweep" in sys.argv:
+    # the write path by its knobs, same process, warm: threads per pwrite, fallocate before the member is written
+    sweep = []
+    for threads, nofalloc in ((8, 1), (8, 0), (16, 0), (16, 1), (4, 0)):
+        native.Context.IO_THREADS = threads
+        if nofalloc:
+            os.environ["ZOT_NO_FALLOCATE"] = "1"
+        else:
+            os.environ.pop("ZOT_NO_FALLOCATE", None)
+        if os.path.exists("/tmp/a.k25"):
+            os.remove("/tmp/a.k25")
+        t, _, ph = run("kmerize", 25, "/tmp/a.k25", "/tmp/a.fastq")
+        sweep.append({"io_threads": threads, "fallocate": not nofalloc, "kmerize_s": round(t, 3),
+                      "device_to_file_ms": round(sum(v for k, v in ph.items() if "file" in k), 1)})
+    out["io_sweep"] = sweep
+    os.environ.pop("ZOT_NO_FALLOCATE", None)
 out["k25_bytes"] = os.path.getsize("/tmp/a.k25")
 if not only_kmerize:
     out["merge_s"], _, ph = run("merge", "/tmp/m.k25", "/tmp/a.k25", "/tmp/b.k25")

@@ -17,6 +17,7 @@
 // No device kernel here except the newline scan; everything else is threads, pread/pwrite, zlib and hipMemcpyAsync.
 #include <errno.h>
 #include <fcntl.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -309,6 +310,8 @@ int zk_device_to_file(zk_ctx* c, const void* d_src, uint64_t bytes, int fd, uint
     if (!d_src || fd < 0) return fail(c, ZK_EINVAL, "zk_device_to_file: bad argument");
     Ring* r;
     ZK_TRY(ring_get(c, &r));
+    // the file's blocks in one request instead of one extension per pwrite slice (where the file system can: errors are not errors here)
+    if (!getenv("ZOT_NO_FALLOCATE")) (void)fallocate(fd, 0, (off_t)file_offset, (off_t)bytes);
     ZK_HIP(c, hipStreamSynchronize(c->stream));              // the producer of d_src ran on the compute stream
     const uint64_t chunks = div_up(bytes, RING_SLOT);
     auto d2h = [&](uint64_t k) -> hipError_t {

@@ -289,7 +289,7 @@ class Context:
         self._check(self.lib.zk_upload_async(self.h, dst.ptr, src_ptr, int(nbytes)))
 
     # ---- ingest: files <-> device memory (csrc/ingest.hip) -------------------------------------------------
-    IO_THREADS = max(1, min(8, (os.cpu_count() or 2) - 1))
+    IO_THREADS = int(os.environ.get("ZOT_IO_THREADS", 0)) or max(1, min(8, (os.cpu_count() or 2) - 1))
 
     def source_open(self, path, threads=None):
         return Source(self, path, threads or self.IO_THREADS)
