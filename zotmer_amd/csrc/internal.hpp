@@ -166,8 +166,9 @@ int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int
                 uint64_t* n_in = nullptr, uint64_t max_chunks = 0, const u32* tags = nullptr, const u64* tag_cuts = nullptr);
 // the keys back from their tags: key = (block number << tag_bits) | tag
 int expand_tags(zk_ctx* c, const u32* tags, const u64* cuts, uint32_t blocks, int tag_bits, u64* keys_out, uint64_t first_block = 0, uint64_t n_blocks = 0);
+// packed_out: out_k takes the words themselves, (key << pack) | count, and out_c is not written (the caller merges them as they are)
 int dedupe_finish(zk_ctx* c, const DedupeResult& r, u64* out_k, u32* out_c, u64* out_m = nullptr, int K = 0, int gbases = 0,
-                  u64** mirror_hist = nullptr, int* mirror_group_bits = nullptr);
+                  u64** mirror_hist = nullptr, int* mirror_group_bits = nullptr, bool packed_out = false);
 int sort_keys_upper_counted(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, int lo_bit, u64* counted, u64** result);
 int collapse_pass(zk_ctx* c, const u64* keys, uint64_t n, int shift, int bits, int pack, u64* out, uint64_t cap, uint64_t* n_out,
                   uint64_t max_tiles = 0);
@@ -228,6 +229,7 @@ int union_sum(zk_ctx* c, const u64* A, const void* cA, u64 nA, const u64* B, con
 // 32-bit counts; the B side is ONE array of (key << pack) | count words
 int union_sum_packed_b(zk_ctx* c, const u64* A, const u32* cA, u64 nA, const u64* Bp, u64 nB, int pack, u64* ok, u32* oc, uint64_t cap,
                        uint64_t* n_out);
+int union_sum_packed_ab(zk_ctx* c, const u64* Ap, u64 nA, const u64* Bp, u64 nB, int pack, u64* ok, u32* oc, uint64_t cap, uint64_t* n_out);
 int column_sum(zk_ctx* c, const u64* rows, uint64_t n_rows, int cols, u64* out);   // out[c] = sum of rows[r][c]
 int project(zk_ctx* c, const u64* ref, u64 n_ref, const u64* B, const u64* cB, u64 nB, u64* ok, u64* oc, uint64_t cap, uint64_t* n_out);
 int intersect_count(zk_ctx* c, const u64* A, u64 nA, const u64* B, u64 nB, uint64_t abc[3]);

@@ -334,6 +334,7 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     bool in_aux = false;          // the counted list lives in the aux region (collapse path): both sort buffers are free
     uint64_t max_count = 0;       // largest count of the list, when it came for free (packed reduce)
     bool have_max = false;
+    bool canon_packed = false;                       // ... and then the counted canonical list is (k-mer << pack | count) words as well
     u64 *mwords = nullptr, *malt = nullptr;          // the mirrored words, grouped by their low MIRROR_GROUP_BITS, when dedupe_finish wrote them
     u64* mhist = nullptr;                            // ... and the digit counts of the passes that sort them, when it took those as well
     int mgroup = MIRROR_GROUP_BITS;                  // ... the low bits they are grouped by (6 more when the blocks told how they split)
@@ -358,8 +359,9 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
                 // grouping copy) for free; they go over the keys' buffer (the keys are counted, the words are in the other one).
                 const bool want_m = !(r.flags & 2) && !canonical_only && c->packed_pairs && dedupe_bit == MIRROR_GROUP_BITS &&
                                     2 * K >= MIRROR_GROUP_BITS + 8;
-                ZK_TRY(dedupe_finish(c, r, (u64*)aux, (u32*)(aux + a8), want_m ? sorted : nullptr, K, MIRROR_GROUP_BASES, &mhist, &mgroup));
-                if (want_m) { mwords = sorted; malt = other; }
+                // ... and the counted list itself stays in words, (k-mer << pk) | count: nobody but the final union reads it
+                ZK_TRY(dedupe_finish(c, r, (u64*)aux, (u32*)(aux + a8), want_m ? sorted : nullptr, K, MIRROR_GROUP_BASES, &mhist, &mgroup, want_m));
+                if (want_m) { mwords = sorted; malt = other; canon_packed = true; }
                 sorted = (u64*)aux; cnt = (u32*)(aux + a8);
                 in_aux = true;
                 if (!(r.flags & 2)) { max_count = (1ull << pk) - 1; have_max = true; }          // every count fits the field
@@ -483,6 +485,7 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
         u64* sk = nullptr;
         if (mhist) ZK_TRY(sort_keys_upper_counted(c, mwords, malt, uc, 2 * K + pk, mgroup + pk, mhist, &sk));
         else ZK_TRY(sort_keys_upper(c, mwords, malt, uc, 2 * K + pk, mgroup + pk, &sk));
+        if (canon_packed) return union_sum_packed_ab(c, sorted, uc, sk, uc, pk, out_k, out_c, cap, n_out);
         return union_sum_packed_b(c, sorted, cnt, uc, sk, uc, pk, out_k, out_c, cap, n_out);
     }
     const uint64_t a8 = (8 * uc + 255) & ~255ull, a4 = (4 * uc + 255) & ~255ull;

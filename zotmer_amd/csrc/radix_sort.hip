@@ -1233,7 +1233,7 @@ __global__ __launch_bounds__(1024, 4) void dedupe_kernel(DedupeArgs a) {
 __global__ __launch_bounds__(256) void dedupe_unpack_kernel(const u64* __restrict__ in, const u64* __restrict__ cuts, const u64* __restrict__ incl,
                                                             const u64* __restrict__ nwords, u32 chunks, int pack, u64* __restrict__ out_k,
                                                             u32* __restrict__ out_c, u64* __restrict__ out_m, const u64* __restrict__ minc,
-                                                            int K, int gbases, MirrorHist mh, const u64* __restrict__ place24) {
+                                                            int K, int gbases, MirrorHist mh, const u64* __restrict__ place24, int packed_out) {
     __shared__ u32 bins[4 * 512];          // the digit histograms of the mirror sort's passes: it reads every word anyway
     const bool hist = out_m && mh.passes > 0;
     if (hist) {
@@ -1260,8 +1260,8 @@ __global__ __launch_bounds__(256) void dedupe_unpack_kernel(const u64* __restric
                 const u64 i = i0 + (u64)q * blockDim.x;
                 if (i >= cnt) break;
                 const u64 w = w4[q];
-                out_k[dst0 + i] = w >> pack;
-                out_c[dst0 + i] = (u32)(w & maxc);
+                if (packed_out) out_k[dst0 + i] = w;          // (the union reads the words as they are: 12 bytes less moved per entry)
+                else { out_k[dst0 + i] = w >> pack; out_c[dst0 + i] = (u32)(w & maxc); }
                 if (out_m) {
                     const u64 mw = (revcomp(K, w >> pack) << pack) | (w & maxc);
                     // place24: grouped by 6 more bits -- the block is sorted, so the words that share their next three bases are
@@ -2302,7 +2302,7 @@ int dedupe_pass(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int b, int
 // out_m (or null; K odd or even, 2 * gbases block bits = all 4^gbases blocks counted): the mirrored words, grouped by their low
 // 2 * gbases bits (dedupe_unpack_kernel) -- ready for the passes over the bits above
 int dedupe_finish(zk_ctx* c, const DedupeResult& r, u64* out_k, u32* out_c, u64* out_m, int K, int gbases, u64** mirror_hist,
-                  int* mirror_group_bits) {
+                  int* mirror_group_bits, bool packed_out) {
     if (mirror_hist) *mirror_hist = nullptr;
     int gbits = 2 * gbases;
     if (mirror_group_bits) *mirror_group_bits = gbits;
@@ -2339,9 +2339,10 @@ int dedupe_finish(zk_ctx* c, const DedupeResult& r, u64* out_k, u32* out_c, u64*
         hipLaunchKernelGGL(dedupe_mirror_sizes_kernel, dim3((r.chunks + 255) / 256), dim3(256), 0, c->stream, r.nwords, r.chunks, gbases, minc);
         ZK_TRY(scan64_inclusive(c, minc, r.chunks));
     }
-    prof_begin(c, ZK_PROF_SELECT, (out_m ? 28 : 20) * r.n_out);
+    if (packed_out && r.n_big) return fail(c, ZK_EINTERNAL, "dedupe_finish: packed words with %u counts beyond the field", r.n_big);
+    prof_begin(c, ZK_PROF_SELECT, ((out_m ? 28 : 20) - (packed_out ? 4 : 0)) * r.n_out);
     hipLaunchKernelGGL(dedupe_unpack_kernel, dim3((u32)c->num_cus * 8), dim3(256), 0, c->stream, r.work, r.cuts, r.incl, r.nwords, r.chunks, r.pack, out_k, out_c,
-                       out_m, minc, K, gbases, mh, place24);
+                       out_m, minc, K, gbases, mh, place24, packed_out ? 1 : 0);
     if (r.n_big) hipLaunchKernelGGL(dedupe_big_kernel, dim3((r.n_big + 255) / 256), dim3(256), 0, c->stream, r.big, r.n_big, out_k, (u64)r.n_out, out_c, c->d_err);
     prof_end(c);
     ZK_HIP(c, hipGetLastError());

@@ -25,9 +25,9 @@ constexpr int MRG_TILE = MRG_BLOCK * MRG_ITEMS;
 constexpr int MRG_NW = MRG_BLOCK / 64;
 
 // part[t] = number of A elements among the first min(t*TILE, nA+nB) merged elements
-// packb > 0: B holds (key << packb) | count words; only the key takes part in the comparisons
+// packb > 0: B holds (key << packb) | count words; only the key takes part in the comparisons (packa: the same for A)
 __global__ void merge_partition_kernel(const u64* __restrict__ A, u64 nA, const u64* __restrict__ B, u64 nB, u64* __restrict__ part,
-                                       u32 tiles, int packb) {
+                                       u32 tiles, int packb, int packa) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > tiles) return;
     u64 D = (u64)t * MRG_TILE;
@@ -35,7 +35,7 @@ __global__ void merge_partition_kernel(const u64* __restrict__ A, u64 nA, const 
     u64 lo = D > nB ? D - nB : 0, hi = D < nA ? D : nA;
     while (lo < hi) {
         const u64 mid = (lo + hi) >> 1;
-        if (A[mid] <= (B[D - mid - 1] >> packb)) lo = mid + 1; else hi = mid;
+        if ((A[mid] >> packa) <= (B[D - mid - 1] >> packb)) lo = mid + 1; else hi = mid;
     }
     part[t] = lo;
 }
@@ -65,6 +65,7 @@ struct MergeSmem {
 struct MergeState {
     u64* status; u32* ticket; u32 ticket_base; u32 epoch; u32* err; u64* d_total; u32 tiles;
     int packb;      // > 0: the B side is one array of (key << packb) | count words (cB is not read)
+    int packa;      // > 0: so is the A side (cA is not read)
 };
 
 // MODE 0: union with summed counts.  MODE 1: projection (project.project2, zotmer/commands/project.py:29-40):
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(MRG_BLOCK) void union_sum_kernel(const u64* __restr
     {
         constexpr int R = (MRG_TILE + 2 + MRG_BLOCK - 1) / MRG_BLOCK;
         const u64* safe_k = nA ? A : B;
-        const CT* safe_c = (nA || st.packb) ? cA : cB;
+        const CT* safe_c = (nA || st.packb) ? cA : cB;          // (packa: cA is the caller's dummy, a readable word)
         u64 kv[R];
         CT cv[R];
 #pragma unroll
@@ -104,12 +105,16 @@ __global__ __launch_bounds__(MRG_BLOCK) void union_sum_kernel(const u64* __restr
             const u64 g = isA ? a0 + (u64)sl : b0 + (u64)(sl - nAt - 1);          // A side: element index + 1
             const bool ok = (sl < nAt + nBt + 2) && (isA ? g >= 1 : g < nB);
             const u64* pk = ok ? (isA ? A + (g - 1) : B + g) : safe_k;
-            const CT* pc = (ok && (isA || !st.packb)) ? (isA ? cA + (g - 1) : cB + g) : safe_c;
+            const CT* pc = (ok && (isA ? !st.packa : !st.packb)) ? (isA ? cA + (g - 1) : cB + g) : safe_c;
             kv[r] = *pk;
             cv[r] = *pc;
             if (st.packb && ok && !isA) {
                 cv[r] = (CT)(kv[r] & ((1ull << st.packb) - 1ull));
                 kv[r] >>= st.packb;
+            }
+            if (st.packa && ok && isA) {
+                cv[r] = (CT)(kv[r] & ((1ull << st.packa) - 1ull));
+                kv[r] >>= st.packa;
             }
             if (!ok) { kv[r] = 0; cv[r] = 0; }
         }
@@ -294,18 +299,18 @@ int column_sum(zk_ctx* c, const u64* rows, uint64_t n_rows, int cols, u64* out) 
     return ZK_OK;
 }
 
-static int make_partition(zk_ctx* c, const u64* A, u64 nA, const u64* B, u64 nB, u64** part, u32* tiles, int packb = 0) {
+static int make_partition(zk_ctx* c, const u64* A, u64 nA, const u64* B, u64 nB, u64** part, u32* tiles, int packb = 0, int packa = 0) {
     *tiles = (u32)div_up(nA + nB, MRG_TILE);
     ZK_TRY(arena_alloc(c, sizeof(u64) * ((uint64_t)*tiles + 1), (void**)part));
     hipLaunchKernelGGL(merge_partition_kernel, dim3((u32)div_up((uint64_t)*tiles + 1, 256)), dim3(256), 0, c->stream, A, nA, B, nB,
-                       *part, *tiles, packb);
+                       *part, *tiles, packb, packa);
     ZK_HIP(c, hipGetLastError());
     return ZK_OK;
 }
 
 template <typename CT, int MODE>
 static int union_sum_t(zk_ctx* c, const u64* A, const CT* cA, u64 nA, const u64* B, const CT* cB, u64 nB, u64* ok, CT* oc,
-                       uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4], int packb = 0) {
+                       uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4], int packb = 0, int packa = 0) {
     *n_out = 0;
     if (acgt_w) acgt_w[0] = acgt_w[1] = acgt_w[2] = acgt_w[3] = 0;
     if (nA + nB == 0) return ZK_OK;
@@ -314,15 +319,16 @@ static int union_sum_t(zk_ctx* c, const u64* A, const CT* cA, u64 nA, const u64*
         const uint64_t need = 40ull * (div_up(nA + nB, MRG_TILE) + 2) + 4096;
         ZK_TRY(arena_require(c, need, need));
     }
-    ZK_TRY(make_partition(c, A, nA, B, nB, &part, &tiles, packb));
+    ZK_TRY(make_partition(c, A, nA, B, nB, &part, &tiles, packb, packa));
     MergeState st;
     st.tiles = tiles;
     st.packb = packb;
+    st.packa = packa;
     ZK_TRY(lookback_begin(c, tiles, tiles, &st.epoch, &st.ticket_base));
     st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9;
     u64* d_rows = nullptr;
     if (acgt_w) ZK_TRY(arena_alloc(c, 32ull * tiles, (void**)&d_rows));
-    prof_begin(c, ZK_PROF_UNION, (8 + sizeof(CT)) * nA + (packb ? 8 : 8 + sizeof(CT)) * nB);
+    prof_begin(c, ZK_PROF_UNION, (packa ? 8 : 8 + sizeof(CT)) * nA + (packb ? 8 : 8 + sizeof(CT)) * nB);
     hipLaunchKernelGGL((union_sum_kernel<CT, MODE>), dim3(tiles), dim3(MRG_BLOCK), 0, c->stream, A, cA, nA, B, cB, nB, part, ok, oc,
                        (u64)cap, d_rows, st);
     prof_end(c);
@@ -348,6 +354,12 @@ int union_sum(zk_ctx* c, const u64* A, const void* cA, u64 nA, const u64* B, con
 int union_sum_packed_b(zk_ctx* c, const u64* A, const u32* cA, u64 nA, const u64* Bp, u64 nB, int pack, u64* ok, u32* oc, uint64_t cap,
                        uint64_t* n_out) {
     return union_sum_t<u32, 0>(c, A, cA, nA, Bp, cA, nB, ok, oc, cap, n_out, nullptr, pack);
+}
+
+// both sides as (key << pack) | count words (the counted canonical list as the block dedupe leaves it, and its mirror image)
+int union_sum_packed_ab(zk_ctx* c, const u64* Ap, u64 nA, const u64* Bp, u64 nB, int pack, u64* ok, u32* oc, uint64_t cap, uint64_t* n_out) {
+    const u32* dummy = reinterpret_cast<const u32*>(nA ? Ap : Bp);          // a readable address for the count loads that are not made
+    return union_sum_t<u32, 0>(c, Ap, dummy, nA, Bp, dummy, nB, ok, oc, cap, n_out, nullptr, pack, pack);
 }
 
 // the reference's counts are not read in MODE 1, so the keys stand in for A's (absent) count array
