@@ -714,7 +714,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_kernel(SortArgs a) {
             for (int g = 0; g < G; g++) gpos[i0 + g] = sm.gbase[(u32)(kk[g] >> a.shift) & dmask] + lo + (tid + (i0 + g) * BLOCK);
 #pragma unroll
             for (int g = 0; g < G; g++)
-                if (lo + tid + (i0 + g) * BLOCK < total) a.kout[gpos[i0 + g]] = kk[g];
+                if (lo + tid + (i0 + g) * BLOCK < total && gpos[i0 + g] < a.n) a.kout[gpos[i0 + g]] = kk[g];          // (< n: a look-back that gave up -- ZK_DERR_SPIN_TIMEOUT -- left offsets that mean nothing)
         }
         if (PAIRS) {
             __syncthreads();
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_kernel(SortArgs a) {
 #pragma unroll
             for (int i = 0; i < IPR; i++) {
                 const u32 s = tid + i * BLOCK;
-                if (lo + s < total) a.vout[gpos[i]] = exv[s];
+                if (lo + s < total && gpos[i] < a.n) a.vout[gpos[i]] = exv[s];
             }
         }
     }
@@ -1375,6 +1375,7 @@ struct PipeSmem {
     u32 wsum[C::NW];
     u32 ticket;
     u32 total_live;
+    u32 abort;                      // a wait for offsets gave up (ZK_DERR_SPIN_TIMEOUT): the workgroup stores nothing from then on
 };
 
 // VAR: 1 only names the instantiation = the upper-bit passes over collapsed lists of packed words, so that a profiler lists them
@@ -1399,6 +1400,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
     // round trip; the slow parts -- global loads and store acknowledgements -- overlap across the waves.
     // Scanners hold the oldest tickets of the launch, hence they are resident, and every count they wait
     // for is published by a workgroup that holds a ticket.
+    if (tid == 0) sm.abort = 0;
     const u32 first = take_ticket(a.ticket, &sm.ticket) - a.ticket_base;
     if (first < (u32)NS) {
         constexpr int U = 32;
@@ -1643,7 +1645,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                     u64 w = vB ? rowA[j] : ld_agent(q);
                     int spins = 0;
                     while (st_state(w, a.epoch) == 0) {
-                        if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT | (32u << 8)); break; }
+                        if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT | (32u << 8)); sm.abort = 1; break; }
                         __builtin_amdgcn_s_sleep(1);
                         w = ld_agent(q);
                     }
@@ -1673,6 +1675,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                 run += tcB[j];
             }
         }
+        if (have && sm.abort) totalA = 0;          // offsets that never came mean nothing: no store is made with them (the launch reports the error)
         if (have) {
             PSTAMP(tileA, 6);
             // The slot index is made opaque: otherwise the compiler precomputes the sixteen `kout + slot` addresses
