@@ -63,7 +63,43 @@ def test_config2_full_size(ctx):
         assert k0.n == n_first and ctx.checksum(k0, c0) == want and ctx.first_descent(k0) == k0.n
     finally:
         ctx.tune(stream_pass=1)
+    # ... from the second pass over static segments (tag_pass.hip; pass 0 then writes two arrays), and from the block dedupe with
+    # one workgroup per CU (round 3's kernel; the default, dedupe2_kernel, made the first result)
+    for knob in (dict(tag_pass=1), dict(dedupe_variant=-1)):
+        try:
+            ctx.tune(**knob)
+            k0, c0, _ = ctx.kmerize(d, K, out=out)
+            assert k0.n == n_first and ctx.checksum(k0, c0) == want and ctx.first_descent(k0) == k0.n, knob
+        finally:
+            ctx.tune(tag_pass=0, dedupe_variant=0)
     del k0, c0, k, c, out, d
+    ctx.release_workspace()
+
+
+def test_config4_share_full_size(ctx):
+    """One GPU's share of BASELINE config 4 (commands/merge.py:127-163): 8 sets of 50 M (k-mer, 64-bit count) pairs, union-summed in
+    one pass (kway.hip) and by the tree of 2-way passes: the same table, its checksum of checksums the sum of the inputs', strictly
+    ascending."""
+    sets, sums, total = [], [0, 0, 0], 0
+    for s in range(8):
+        a = synth.config4_set_args(s, 1.0)
+        k, c = ctx.synth_set(a["seed"], a["first"], a["count"], a["key_bits"], mul=a["mul"], add=a["add"], mod=a["mod"])
+        sets.append((k, c))
+        for i, v in enumerate(ctx.checksum_counts(k, c)):
+            sums[i] = (sums[i] + v) & ((1 << 64) - 1)
+        total += k.n
+    out = (ctx.empty(total, np.uint64), ctx.empty(total, np.uint64))
+    got = {}
+    try:
+        for kway in (1, 0):
+            ctx.tune(kway=kway)
+            mk, mc, acgt = ctx.merge_n(sets, out=out)
+            assert list(ctx.checksum_counts(mk, mc)) == sums and ctx.first_descent(mk) == mk.n and sum(acgt) == sums[0], kway
+            got[kway] = (mk.n, ctx.checksum_counts(mk, mc), list(acgt))
+    finally:
+        ctx.tune(kway=1)
+    assert got[1] == got[0]
+    del sets, out
     ctx.release_workspace()
 
 
