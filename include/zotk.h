@@ -96,6 +96,9 @@ int zk_upload_async(zk_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
                                   * in all (profiles/r04/tag_pass_ab.json: the second pass gains 5 ms, pass 0 loses 8.5) */
 #define ZK_TUNE_KWAY 18          /* zk_merge_n: 1 (default) = inputs of 4 Mi pairs or more are union-summed up to 16 lists at a time, in one pass over the data
                                   * (kway.hip); 2 = every input (tests); 0 = always the tree of 2-way passes */
+#define ZK_TUNE_TILE_SORT 19     /* sorts of keys that do not repeat (zk_sort_keys, zk_kmerize on such reads): 1 (default) = LSD passes over the top bits
+                                  * only, until blocks of equal top bits are a few dozen keys, then every tile of ~6 K keys sorted to the end in LDS
+                                  * (tilesort.hip); 0 = LSD passes over every bit */
 #define ZK_TUNE_COMM_SELF_LOOP 16 /* tests: 1 = the piece a rank keeps goes through grouped ncclSend / ncclRecv to itself, in the same rounds as
                                   * the other pieces (instead of a device copy), and zk_allreduce_u64 calls ncclAllReduce with one rank too:
                                   * the RCCL data path of zk_comm_* executed on a box with one GPU; 0 (default) */
@@ -116,6 +119,7 @@ int zk_tune(zk_ctx* ctx, int what, int value);
 #define ZK_PROF_COUNT_HIST 11
 #define ZK_PROF_PASS_PACKED 12  /* radix pass of the key kernel over a collapsed list of (k-mer << s | count) words (16 B per word) */
 #define ZK_PROF_SAMPLE 13       /* the look before the sort: the few set-aside blocks, sorted and counted (tiny launches) */
+#define ZK_PROF_TILE_SORT 14    /* the lower bits of a sort finished tile by tile in LDS (tilesort.hip: 16 B per key, 24 per pair, once) */
 int zk_debug_buffer(zk_ctx* ctx, void* d_buf);   /* diagnostic builds (-DZK_STAMPS) only; NULL turns it off */
 int zk_profile(zk_ctx* ctx, int enable);   /* clears the records; enable != 0 starts recording */
 int zk_profile_read(zk_ctx* ctx, int tag, uint64_t* launches, double* total_ms, uint64_t* algorithmic_bytes);

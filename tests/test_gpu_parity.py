@@ -167,6 +167,46 @@ def test_sort_pairs_is_stable(ctx, n):
     assert np.array_equal(dv.to_host(), v[order])
 
 
+def _tile_sort_inputs(rng, n, bits):
+    """inputs of the sort that is finished tile by tile in LDS (tilesort.hip): spread evenly, every key about three times, a few
+    crowded stretches of the key space (blocks of equal top bits of up to ~1000 keys: the tile's groups are then uneven), one block
+    too long for a tile (the sort must notice and take the long way)"""
+    mask = np.uint64((1 << bits) - 1)
+    top = np.uint64(bits - 18 if bits > 27 else 9)
+    uni = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+    yield "uniform", uni & mask
+    yield "triples", (rng.integers(0, max(1, n // 3), size=n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) & mask
+    x = uni & mask
+    m = min(n // 2, 40 * 900)
+    pre = rng.integers(0, 1 << 18, size=40, dtype=np.uint64) << top
+    x[:m] = (np.repeat(pre, 900)[:m] | (x[:m] & ((np.uint64(1) << top) - np.uint64(1)))) & mask
+    yield "crowded", x
+    y = x.copy()
+    y[n // 2: n // 2 + 1500] = (y[n // 2] >> top << top) | (y[n // 2: n // 2 + 1500] & np.uint64((1 << min(16, int(top))) - 1))
+    yield "too_long", y
+
+
+@pytest.mark.parametrize("bits", [30, 50, 62, 64])
+@pytest.mark.parametrize("n", [65536, 65536 + 7168 + 3, 2_500_001])
+def test_sort_finished_in_tiles(ctx, n, bits):
+    """zk_sort_keys / zk_sort_pairs on arrays large enough for the tile sort (LSD passes over the top bits, the rest in LDS) against
+    numpy's sort (library/misc.py:400-424); the pairs stay in their order of arrival when keys are equal; and the same with the
+    tile sort switched off"""
+    rng = np.random.default_rng(n * 7 + bits)
+    for name, x in _tile_sort_inputs(rng, n, bits):
+        want = np.sort(x)
+        assert np.array_equal(ctx.sort_keys(ctx.upload(x), bits).to_host(), want), name
+        v = np.arange(n, dtype=np.uint32)
+        dk, dv = ctx.sort_pairs(ctx.upload(x), ctx.upload(v), bits)
+        order = np.argsort(x, kind="stable")
+        assert np.array_equal(dk.to_host(), want) and np.array_equal(dv.to_host(), v[order]), name
+    try:
+        ctx.tune(tile_sort=0)
+        assert np.array_equal(ctx.sort_keys(ctx.upload(x), bits).to_host(), np.sort(x))
+    finally:
+        ctx.tune(tile_sort=1)
+
+
 # ---- K4 run-length count ---------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("in_place", [False, True])

@@ -36,6 +36,7 @@ struct zk_ctx {
                                // keys as two arrays (6 bytes a key); 0 (default) = the look-back pipeline over whole keys.  Measured
                                // (profiles/r04/tag_pass_ab.json): the pass 25.0 -> 17.4 + 2.2 ms, but pass 0 21.3 -> 29.8 ms (half-line units)
     int kway = 1;              // zk_merge_n: 1 = up to 16 lists per pass (kway.hip) from 4 Mi pairs on, 2 = always, 0 = the tree of 2-way passes
+    int tile_sort = 1;         // sorts of keys that do not repeat: LSD passes over the top bits, then tiles sorted to the end in LDS (tilesort.hip)
     int dedupe_bits = 0;       // tests: > 0 = the block dedupe with this many block bits whatever the input's size (pipeline.hip)
     int stream_ranges = 0;     // ... ranges the stream is cut into (0 = two per CU; tests use a few so that a range has many tiles)
 
@@ -137,12 +138,14 @@ int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n,
 int sort_keys_upper(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, int lo_bit, u64** result, int prof_tag = ZK_PROF_PASS_PACKED);
 int sort_pairs_upper(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, int lo_bit, u64** rk, u32** rv);
 int sort_pairs_mirrored(zk_ctx* c, const u64* src_k, const u32* src_v, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int K,
-                        u64** rk, u32** rv);
+                        u64** rk, u32** rv, int lo_bit = 0);
+int sort_pairs_rbits(zk_ctx* c);
 // sort whose first pass generates the keys from a base stream (encode.hip + radix_sort.hip)
 // Ask sort_stream to look before it sorts: the histogram kernel sets aside the keys whose bits from `shift` up equal `value` (a
 // few whole blocks of the block dedupe: every copy of their k-mers), and if more than max_ratio of them are distinct the sort is
 // declined (return 1, nothing sorted) -- the caller then plans for an input that does not repeat its k-mers.
-struct StreamSample { int shift; uint64_t value; double max_ratio; uint64_t seen = 0, distinct = 0; };
+// want_distinct: the other way round -- the sort goes ahead if the set-aside keys are (nearly) all distinct and is declined if they repeat.
+struct StreamSample { int shift; uint64_t value; double max_ratio; uint64_t seen = 0, distinct = 0; bool want_distinct = false; };
 // Ask sort_stream to let the last of its two passes write the keys' low 32 bits only (the bits [32, 2K) are the ones sorted:
 // lo_bit == 32): *result is then a u32 array, and `cuts` says where each block of equal sorted bits starts (see tag_cuts_kernel).
 struct StreamTags { bool written = false; u64* cuts = nullptr; uint32_t blocks = 0; };
@@ -186,6 +189,9 @@ int stream_pass0(zk_ctx* c, uint64_t n_bytes, int K, int mode, int shift, int bi
                  uint64_t first_nl, bool uniform, u64* kout, uint64_t n, int variant, const StreamPlanes* planes = nullptr);
 // tag_pass.hip: the second pass of the two-pass plan over pass 0's two arrays; writes the tags ordered by (d1, d0) and the blocks' starts
 int stream_pass1(zk_ctx* c, const u32* tags, const u16* dig, uint64_t n, const u64* ghist0, uint32_t radix0, int bits1, u32* tout, u64* cuts);
+// tilesort.hip: the lower bits of a sort, tile by tile in LDS
+int tile_sort_top_bits(uint64_t n, int key_bits, int rbits);   // the top bits the LSD passes must have sorted first (0 = not worth it)
+int tile_sort(zk_ctx* c, u64* keys, u32* vals, uint64_t n, int key_bits, int top, bool* declined);   // in place
 // select.hip
 int trim(zk_ctx* c, const u64* keys, const void* cnts, int cbits, uint64_t n, u64 lo, u64 hi, u64* ok, void* oc,
          uint64_t cap, uint64_t* n_out);

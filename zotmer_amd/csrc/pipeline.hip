@@ -179,6 +179,16 @@ static int mirror_union(zk_ctx* c, const u64* sorted, const u32* cnt, uint64_t u
                         u64* out_k, u32* out_c, uint64_t cap, uint64_t* n_out, int pack = 0) {
     u64* sk; u32* sv;
     if (!(2 * K >= MIRROR_GROUP_BITS + 8 && uc >= (1ull << 16))) pack = 0;
+    // As pairs (K >= 28, or counts too large for the field) and long enough: the mirrored keys are all different, so the tile sort
+    // applies -- three passes over the top bits, reverse-complemented on load, then the rest in LDS -- instead of the grouping copy
+    // and five passes.  Should a tile decline (it cannot on distinct keys unless they crowd under one prefix), the passes do it all.
+    const int ttop = (!pack && c->tile_sort) ? tile_sort_top_bits(uc, 2 * K, sort_pairs_rbits(c)) : 0;
+    if (ttop) {
+        bool declined = false;
+        ZK_TRY(sort_pairs_mirrored(c, sorted, cnt, rk, rk2, rv, rv2, uc, K, &sk, &sv, 2 * K - ttop));
+        ZK_TRY(tile_sort(c, sk, sv, uc, 2 * K, ttop, &declined));
+        if (declined) ZK_TRY(sort_pairs_mirrored(c, sorted, cnt, rk, rk2, rv, rv2, uc, K, &sk, &sv));
+    } else
     if (2 * K >= MIRROR_GROUP_BITS + 8 && uc >= (1ull << 16)) {
         // The list (c, n) is sorted by c, so the k-mers that share their first 9 bases are contiguous -- and those are
         // exactly the mirrored keys rc(c) that share their LAST 9 bases, i.e. their low 18 bits.  The first two passes of
@@ -301,6 +311,7 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     uint64_t n = 0;
     u64* sorted = nullptr;
     bool presampled = false;
+    int tile_top = 0;          // > 0: LSD passes over these top bits only, then tile_sort
     StreamTags stags;          // set when the last pass wrote 32-bit tags instead of keys (`sorted` is then a u32 array)
     if (dedupe_bit) {
         // Sorting the top bits first only pays if the blocks can then be counted; an input that does not repeat its k-mers would
@@ -314,10 +325,47 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
         if (rc < 0) return rc;
         src.sample = nullptr;
         src.tags = nullptr;
-        if (rc == 1) { dedupe_bit = 0; src.lo_bit = 0; }
+        if (rc == 1) {
+            dedupe_bit = 0; src.lo_bit = 0;
+            // the input does not repeat its k-mers: no collapse will pay either, every key goes to the end of the sort -- the top bits
+            // by passes, the rest tile by tile in LDS (tilesort.hip)
+            if (c->tile_sort) tile_top = tile_sort_top_bits(n_bytes, 2 * K, rb);
+        }
         presampled = smp.seen >= 4096;          // the look was conclusive: no second one after the passes
     }
-    if (!dedupe_bit) {
+    bool top_sorted = false;          // sort_stream has run with the tile sort's plan
+    if (!dedupe_bit && !tile_top && !both && c->tile_sort && c->early_collapse && !pack_bits_for(K)) {
+        // No block dedupe for this input (K >= 28: no room for a count beside the k-mer).  Reads that repeat
+        // their k-mers are collapsed after the low passes (below); reads that do not -- a share of a large genome at low coverage:
+        // config 5 -- go the other way: the top bits by passes, the rest tile by tile.  Which it is, a look at the keys under one
+        // prefix tells (about 2^15 of them: every copy of their k-mers), taken by the histogram kernel of the plan that is tried first.
+        const int tt = tile_sort_top_bits(n_bytes, 2 * K, rb);
+        const int lg = ilog2_ceil(n_bytes);
+        const int pb = lg - 15 < 2 ? 2 : (lg - 15 > 30 ? 30 : lg - 15);
+        if (tt && pb < 2 * K) {
+            StreamSample smp{2 * K - pb, (uint64_t)(0x0D71C8E5u >> (32 - pb)), 0.6};
+            smp.want_distinct = true;
+            src.lo_bit = 2 * K - tt; src.hi_bit = 0; src.sample = &smp;
+            const int rc = sort_stream(c, src, buf_a, buf_b, cap_keys, &n, st->acgt, &sorted);
+            if (rc < 0) return rc;
+            src.sample = nullptr;
+            if (rc == 1) src.lo_bit = 0;          // they repeat: the plan below
+            else { tile_top = tt; top_sorted = true; }
+        }
+    }
+    if (!dedupe_bit && tile_top) {
+        src.lo_bit = 2 * K - tile_top; src.hi_bit = 0;
+        if (!top_sorted) ZK_TRY(sort_stream(c, src, buf_a, buf_b, cap_keys, &n, st->acgt, &sorted));
+        bool declined = false;
+        ZK_TRY(tile_sort(c, sorted, nullptr, n, 2 * K, tile_top, &declined));
+        if (declined) {          // a block of equal top bits too long for a tile: every bit by passes, from where the keys are now
+            u64* res = nullptr;
+            ZK_TRY(sort_keys_upper(c, sorted, sorted == buf_a ? buf_b : buf_a, n, 2 * K, 0, &res, ZK_PROF_PASS_KEYS));
+            sorted = res;
+        }
+        fused_bit = 0;
+        collapse_bit = 0;
+    } else if (!dedupe_bit) {
         src.hi_bit = fused_bit ? fused_bit : collapse_bit;
         ZK_TRY(sort_stream(c, src, buf_a, buf_b, cap_keys, &n, st->acgt, &sorted));
     }

@@ -2000,7 +2000,8 @@ struct Sorter {
                 ZK_TRY(sort_keys(c, buf_b, buf_b + sample_cap, sn, 2 * src.K, &res, 0, ZK_PROF_SAMPLE));
                 ZK_TRY(rle(c, res, sn, res, (u32*)(buf_b + 2ull * sample_cap), sn, &distinct));
                 src.sample->distinct = distinct;
-                if ((double)distinct > src.sample->max_ratio * (double)sn) return 1;          // declined: nothing sorted
+                const bool repeats = (double)distinct <= src.sample->max_ratio * (double)sn;
+                if (repeats == src.sample->want_distinct) return 1;          // declined: nothing sorted
             }
         }
         a.kout = buf_a; a.shift = plan.shift[0]; a.bits = plan.bits[0]; a.ghist = ghist;
@@ -2113,16 +2114,45 @@ int launch_wide_pass(zk_ctx* c, const SortArgs& a) { return Sorter<V6>::launch_p
         default: return Sorter<V3>::CALL;           \
     }
 
+static int sort_keys_lsd(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** result) {
+    ZK_SORT_DISPATCH(c, sort_keys(c, keys, alt, n, key_bits, result));
+}
+static int sort_pairs_lsd(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, u64** rk, u32** rv) {
+    ZK_SORT_DISPATCH_V(c->pairs_variant, sort_pairs(c, keys, alt, vals, valt, n, key_bits, rk, rv));
+}
+
+// Large arrays: LSD passes over the top bits only, then every tile sorted to the end in LDS (tilesort.hip) -- unless a block of equal
+// top bits turns out too long for a tile, in which case every bit is sorted by LSD passes after all (from wherever the keys are now).
 int sort_keys(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bits, u64** result) {
     *result = keys;
     if (n == 0) return ZK_OK;
-    ZK_SORT_DISPATCH(c, sort_keys(c, keys, alt, n, key_bits, result));
+    const int top = c->tile_sort ? tile_sort_top_bits(n, key_bits, sort_rbits(c)) : 0;
+    if (top) {
+        u64* res = nullptr;
+        bool declined = false;
+        ZK_TRY(sort_keys_upper(c, keys, alt, n, key_bits, key_bits - top, &res, ZK_PROF_PASS_KEYS));
+        ZK_TRY(tile_sort(c, res, nullptr, n, key_bits, top, &declined));
+        *result = res;
+        if (!declined) return ZK_OK;
+        return sort_keys_lsd(c, res, res == keys ? alt : keys, n, key_bits, result);
+    }
+    return sort_keys_lsd(c, keys, alt, n, key_bits, result);
 }
 
 int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, u64** rk, u32** rv) {
     *rk = keys; *rv = vals;
     if (n == 0) return ZK_OK;
-    ZK_SORT_DISPATCH_V(c->pairs_variant, sort_pairs(c, keys, alt, vals, valt, n, key_bits, rk, rv));
+    const int top = c->tile_sort ? tile_sort_top_bits(n, key_bits, sort_pairs_rbits(c)) : 0;
+    if (top) {
+        u64* k1 = nullptr; u32* v1 = nullptr;
+        bool declined = false;
+        ZK_TRY(sort_pairs_upper(c, keys, alt, vals, valt, n, key_bits, key_bits - top, &k1, &v1));
+        ZK_TRY(tile_sort(c, k1, v1, n, key_bits, top, &declined));
+        *rk = k1; *rv = v1;
+        if (!declined) return ZK_OK;
+        return sort_pairs_lsd(c, k1, k1 == keys ? alt : keys, v1, v1 == vals ? valt : vals, n, key_bits, rk, rv);
+    }
+    return sort_pairs_lsd(c, keys, alt, vals, valt, n, key_bits, rk, rv);
 }
 
 // keys already ordered by their low `lo_bit` bits: LSD passes over the bits above only
@@ -2147,12 +2177,14 @@ int sort_pairs_upper(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint6
 }
 
 // (rc(src_k[i]), src_v[i]) sorted by key; keys/alt/vals/valt are work buffers, the source arrays are only read
+// lo_bit > 0: ordered by the bits [lo_bit, 2K) only (stable passes: tile_sort's input)
 int sort_pairs_mirrored(zk_ctx* c, const u64* src_k, const u32* src_v, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int K,
-                        u64** rk, u32** rv) {
+                        u64** rk, u32** rv, int lo_bit) {
     *rk = keys; *rv = vals;
     if (n == 0) return ZK_OK;
-    ZK_SORT_DISPATCH_V(c->pairs_variant, sort_pairs(c, keys, alt, vals, valt, n, 2 * K, rk, rv, src_k, src_v, K));
+    ZK_SORT_DISPATCH_V(c->pairs_variant, sort_pairs(c, keys, alt, vals, valt, n, 2 * K, rk, rv, src_k, src_v, K, lo_bit));
 }
+int sort_pairs_rbits(zk_ctx* c) { return (c->pairs_variant == 0 || c->pairs_variant == 1 || c->pairs_variant == 5) ? 8 : 9; }
 
 // digit width of the geometry used for key arrays (the truncated sort sizes its bit range with it)
 // the digits sort_keys_upper / sort_keys_upper_counted will use for the bits [lo_bit, key_bits)

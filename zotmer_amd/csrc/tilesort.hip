@@ -1,0 +1,261 @@
+// tilesort.hip -- K2b, finishing a radix sort in LDS.
+//
+// Replaces the lower passes of numpy's sort in kmerize (zotmer/commands/kmerize.py:41-132, `xs.sort()`; library/misc.py:400-424 for the
+// pair lists) exactly as the LSD passes of radix_sort.hip do: same keys in, same sorted keys out.
+//
+// An LSD sort moves every key once per digit: 6 passes of 16 bytes a key at K = 25, 7 at K = 31.  But once the TOP bits are sorted -- by
+// the same stable passes, taken over the bits [key_bits - t, key_bits) only -- the array is a row of blocks of equal top bits in key
+// order, and as soon as a block is a few dozen keys the rest of the sort is local: cut the array into tiles of about T keys AT BLOCK
+// BORDERS (tile_bounds_kernel: a binary search over the S keys before every multiple of T), and a workgroup sorts a tile in LDS all the
+// way, whatever number of bits is left, at 16 bytes a key ONCE.
+//
+// In LDS (tile_sort_kernel) a tile is sorted the way dedupe2_kernel sorts a block's entries: a counting sort into G = 4096 (2048) groups by
+// the key's place in the tile's value range (the tile spans whole blocks, so the range is known from its first and last key's top bits;
+// the keys of a tile are spread evenly enough over it for groups of ~1.5), then every key's rank inside its group by comparing -- the
+// key's own LDS index breaks ties, so equal keys get different places -- and the store goes straight to its final place: the 64 lanes
+// of a wave hold neighbours of the grouped order, so what they write is a permutation of one contiguous 512 bytes.
+//
+// Exact for any input: the result never depends on how the keys are spread (a crowded group only costs compares), and an input with
+// a block of more than S keys -- more than S copies of one top-bit pattern: low-complexity sequence in reads that otherwise do not
+// repeat -- raises a flag instead of being cut wrongly; the caller then sorts the remaining bits the long way (the array is untouched
+// where a tile was too large, a permutation of the input everywhere).
+#include "internal.hpp"
+
+namespace zk {
+
+constexpr int TS_BLOCK = 512;
+constexpr u32 TS_SLACK = 1024;          // S: no block of equal top bits may be longer
+
+// PAIRS: a 32-bit payload travels with every key, and equal keys keep the order they came in (zk_sort_pairs is stable): the
+// place a pair had in the tile is kept beside it and breaks the ties (keys alone need no such thing: equal keys are the same key)
+template <int ITEMS, int GROUPS, bool PAIRS>
+struct TileSortSmem {
+    static constexpr int CAP = TS_BLOCK * ITEMS;
+    alignas(16) u64 keys[CAP];
+    u32 vals[PAIRS ? CAP : 1];
+    u16 idx[PAIRS ? CAP : 1];
+    alignas(16) u32 start[GROUPS + 8];          // the groups' counts, then where they start (start[G] = the tile's keys)
+    u32 wsum[TS_BLOCK / 64];
+};
+typedef TileSortSmem<14, 4096, false> TileSortKeys;
+typedef TileSortSmem<10, 2048, true> TileSortPairs;
+
+struct TileSortArgs {
+    const u64* kin; u64* kout;
+    const u32* vin; u32* vout;
+    const u64* bounds;          // [tiles + 1]
+    u32 tiles;
+    int pshift;                 // the bits from here up are sorted already
+};
+
+// bounds[t] = the first key of the block that the key at t * T belongs to (t = 1 .. tiles - 1); bounds[0] = 0, bounds[tiles] = n
+__global__ void tile_bounds_kernel(const u64* __restrict__ a, u64 n, int pshift, u32 T, u32 S, u32 tiles, u64* __restrict__ bounds,
+                                   u32* __restrict__ flag) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > tiles) return;
+    if (t == 0) { bounds[0] = 0; return; }
+    if (t == tiles) { bounds[tiles] = n; return; }
+    const u64 p = (u64)t * T;          // < n, and >= T > S
+    const u64 pre = a[p] >> pshift;
+    u64 lo = p - S, hi = p;            // a[hi] has the prefix; is a[lo]'s smaller?
+    if ((a[lo] >> pshift) == pre) {
+        atomicOr(flag, 1u);            // a block of more than S keys: not cut here (the tile is then too large and skipped)
+        bounds[t] = lo;
+        return;
+    }
+    while (hi - lo > 1) {              // invariant: prefix(a[lo]) < pre == prefix(a[hi])
+        const u64 mid = lo + (hi - lo) / 2;
+        if ((a[mid] >> pshift) == pre) hi = mid; else lo = mid;
+    }
+    bounds[t] = hi;
+}
+
+template <int ITEMS, int G, bool PAIRS>
+__global__ __launch_bounds__(TS_BLOCK, 2 * TS_BLOCK / 256) void tile_sort_kernel(TileSortArgs a) {
+    using S = TileSortSmem<ITEMS, G, PAIRS>;
+    constexpr int CAP = S::CAP, NW = TS_BLOCK / 64, QPT = G / TS_BLOCK / 4;          // QPT: quads of groups a thread scans
+    static_assert(sizeof(S) <= 80 * 1024, "two workgroups per CU");
+    static_assert(QPT == 1 || QPT == 2, "four or eight groups a thread in the scan");
+    static_assert(CAP <= 8192 && G <= 4096, "group | place << 12 in a word");
+    __shared__ S sm;
+    for (u32 t = blockIdx.x; t < a.tiles; t += gridDim.x) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));          // (opaque per tile: nothing derived from it is kept, as a 64-bit pair, across tiles)
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const u64 lo = a.bounds[t], hi = a.bounds[t + 1];
+        if (hi - lo > (u64)CAP || hi == lo) continue;          // too large: flagged by tile_bounds_kernel, the caller sorts the long way
+        const u32 m = (u32)(hi - lo);
+        const u64* kp = a.kin + lo;
+        u64 k[ITEMS];
+        u32 v[PAIRS ? ITEMS : 1];
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            const u32 i = (u32)j * TS_BLOCK + tid;
+            k[j] = i < m ? kp[i] : ~0ull;
+            if constexpr (PAIRS) v[j] = i < m ? a.vin[lo + i] : 0u;
+        }
+        // the tile's value range, from the top bits of its first and last key (whole blocks), and the map key -> group: monotone,
+        // g = floor(d * G / (range >> sh)) for d = (key - first) >> sh, 32-bit
+        const u64 first = kp[0], last = kp[m - 1];
+        const u64 kmin = (first >> a.pshift) << a.pshift;
+        const u64 rm1 = (((last >> a.pshift) - (first >> a.pshift)) << a.pshift) | ((1ull << a.pshift) - 1ull);
+        const int sh = rm1 >> 32 ? 32 - __builtin_clzll(rm1) : 0;
+        const u32 rs = (u32)(rm1 >> sh);
+        const u32 scale = rs < (u32)G ? 0u : (u32)(((u64)G << 32) / ((u64)rs + 1ull));
+        auto group = [&](u64 key) -> u32 {
+            const u32 d = (u32)((key - kmin) >> sh);
+            return scale ? __umulhi(d, scale) : d;
+        };
+        {
+            uint4* z = reinterpret_cast<uint4*>(sm.start);
+#pragma unroll
+            for (int q = 0; q < QPT; q++) z[QPT * tid + q] = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+        u32 gp[ITEMS];          // group | place in the group << 12
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            const u32 i = (u32)j * TS_BLOCK + tid;
+            const u32 g = i < m ? group(k[j]) : 0u;
+            gp[j] = g;
+            if (i < m) gp[j] |= atomicAdd(&sm.start[g], 1u) << 12;
+        }
+        __syncthreads();
+        {
+            // counts -> starts: four or eight groups a thread, the waves' sums through LDS
+            uint4* z = reinterpret_cast<uint4*>(sm.start);
+            uint4 cq[QPT];
+            u32 sum = 0;
+#pragma unroll
+            for (int q = 0; q < QPT; q++) { cq[q] = z[QPT * tid + q]; sum += cq[q].x + cq[q].y + cq[q].z + cq[q].w; }
+            const u32 inc = wave_incl_scan_u32(sum);
+            if (lane == 63) sm.wsum[wave] = inc;
+            __syncthreads();
+            u32 run = inc - sum;
+#pragma unroll
+            for (int w = 0; w < NW; w++) run += w < wave ? sm.wsum[w] : 0u;
+#pragma unroll
+            for (int q = 0; q < QPT; q++) {
+                uint4 sq;
+                sq.x = run; run += cq[q].x; sq.y = run; run += cq[q].y; sq.z = run; run += cq[q].z; sq.w = run; run += cq[q].w;
+                z[QPT * tid + q] = sq;
+            }
+            if (tid == 0) sm.start[G] = m;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            const u32 i = (u32)j * TS_BLOCK + tid;
+            if (i < m) {
+                const u32 p = sm.start[gp[j] & (G - 1)] + (gp[j] >> 12);
+                sm.keys[p] = k[j];
+                if constexpr (PAIRS) { sm.vals[p] = v[j]; sm.idx[p] = (u16)i; }
+            }
+        }
+        __syncthreads();
+        // ranks: E entries of a thread at a time, so that their LDS round trips (entry, group bounds, the group's first four keys) overlap
+        constexpr int E = 2;
+        u64* op = a.kout + lo;
+        // does the entry at q (key ko) go before the one at i (key km)?  Equal keys: the one that came first (pairs), any fixed order (keys)
+        auto before = [&](u64 ko, u32 q, u64 km, u32 i) -> bool {
+            if (ko != km) return ko < km;
+            if constexpr (PAIRS) return q != i && sm.idx[q] < sm.idx[i];          // (rare: the two extra reads are taken by the lanes that need them)
+            else return q < i;
+        };
+        for (u32 i0 = (u32)tid; i0 < m; i0 += E * TS_BLOCK) {
+            u64 mine[E];
+            u32 g0[E], g1[E], rank[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const u32 i = i0 + e * TS_BLOCK;
+                mine[e] = sm.keys[i < m ? i : 0u];
+            }
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const u32 g = group(mine[e]);
+                g0[e] = sm.start[g]; g1[e] = sm.start[g + 1];
+            }
+            u64 o[E][4];
+#pragma unroll
+            for (int e = 0; e < E; e++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) o[e][r] = sm.keys[g0[e] + r < (u32)CAP ? g0[e] + r : (u32)CAP - 1];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const u32 i = i0 + e * TS_BLOCK;
+                rank[e] = 0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const u32 q = g0[e] + r;
+                    rank[e] += (q < g1[e] && before(o[e][r], q, mine[e], i)) ? 1u : 0u;
+                }
+                for (u32 q0 = g0[e] + 4; q0 < g1[e]; q0 += 4) {          // (a group of more than four)
+                    u64 p4[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) p4[r] = sm.keys[q0 + r < (u32)CAP ? q0 + r : (u32)CAP - 1];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const u32 q = q0 + r;
+                        rank[e] += (q < g1[e] && before(p4[r], q, mine[e], i)) ? 1u : 0u;
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const u32 i = i0 + e * TS_BLOCK;
+                if (i >= m) break;
+                op[g0[e] + rank[e]] = mine[e];
+                if constexpr (PAIRS) a.vout[lo + g0[e] + rank[e]] = sm.vals[i];
+            }
+        }
+        __syncthreads();          // the tile's LDS is free again
+    }
+}
+
+// How many top bits the LSD passes must have sorted before tiles can be cut: whole passes of rbits, blocks of about 64 keys or fewer
+// on average (the canonical k-mers' blocks that start with A are twice the mean; S = 1024 leaves room for the rest).  0 = not worth
+// it (the passes left over would be fewer than two).
+int tile_sort_top_bits(uint64_t n, int key_bits, int rbits) {
+    if (n < (1ull << 16)) return 0;
+    int passes = 1;
+    while ((n >> (rbits * passes)) > 64 && rbits * passes < key_bits) passes++;
+    const int top = rbits * passes;
+    const int all = (key_bits + rbits - 1) / rbits;
+    if (passes + 2 > all || top >= key_bits) return 0;
+    return top;
+}
+
+// keys (and vals, or null) hold n keys ordered by the bits [key_bits - top, key_bits): sorts them by all their bits, in place.
+// *declined = true: a block of equal top bits was too long, the array is a permutation of what it was (still ordered by the top bits
+// where tiles were sorted, untouched elsewhere) and the caller must sort it another way.
+int tile_sort(zk_ctx* c, u64* keys, u32* vals, uint64_t n, int key_bits, int top, bool* declined) {
+    *declined = false;
+    if (n == 0) return ZK_OK;
+    const bool pairs = vals != nullptr;
+    const u32 cap = pairs ? (u32)TileSortPairs::CAP : (u32)TileSortKeys::CAP;
+    const u32 T = cap - TS_SLACK;
+    const uint64_t tiles64 = div_up(n, T);
+    if (tiles64 >= (1ull << 31)) return fail(c, ZK_EINVAL, "tile sort: %llu keys", (unsigned long long)n);
+    const u32 tiles = (u32)tiles64;
+    u64* bounds;
+    ZK_TRY(arena_alloc(c, sizeof(u64) * ((uint64_t)tiles + 1), (void**)&bounds));
+    u32* flag = (u32*)(c->d_scalars + 40);
+    ZK_HIP(c, hipMemsetAsync(flag, 0, sizeof(u64), c->stream));
+    const int pshift = key_bits - top;
+    hipLaunchKernelGGL(tile_bounds_kernel, dim3(tiles / 256 + 1), dim3(256), 0, c->stream, (const u64*)keys, (u64)n, pshift, T, TS_SLACK, tiles, bounds, flag);
+    ZK_HIP(c, hipGetLastError());
+    TileSortArgs a{keys, keys, vals, vals, bounds, tiles, pshift};
+    const u32 want = 2u * (u32)c->num_cus;
+    const u32 grid = tiles < want ? tiles : want;
+    prof_begin(c, ZK_PROF_TILE_SORT, (pairs ? 24 : 16) * n);
+    if (pairs) hipLaunchKernelGGL((tile_sort_kernel<10, 2048, true>), dim3(grid), dim3(TS_BLOCK), 0, c->stream, a);
+    else hipLaunchKernelGGL((tile_sort_kernel<14, 4096, false>), dim3(grid), dim3(TS_BLOCK), 0, c->stream, a);
+    prof_end(c);
+    ZK_HIP(c, hipGetLastError());
+    ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 40, flag, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    ZK_HIP(c, hipStreamSynchronize(c->stream));
+    *declined = (c->h_scalars[40] & 1ull) != 0;
+    return ZK_OK;
+}
+
+}  // namespace zk

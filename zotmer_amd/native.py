@@ -316,11 +316,13 @@ class Context:
 
     # ---- per-launch timing (HIP events on the ctx stream) -----------------------------------
     PROF_TAGS = {"hist_stream": 1, "hist_array": 2, "pass_stream": 3, "pass_keys": 4, "pass_pairs": 5, "rle": 6,
-                 "union_sum": 7, "select": 8, "mirror": 9, "intersect": 10, "count_hist": 11, "pass_packed": 12, "sample": 13}
+                 "union_sum": 7, "select": 8, "mirror": 9, "intersect": 10, "count_hist": 11, "pass_packed": 12, "sample": 13, "tile_sort": 14}
 
     def tune(self, sort_variant=None, pairs_variant=None, short_sort=None, side_div=None, xcd_group=None, comm_chunk=None,
              early_collapse=None, packed_pairs=None, wide_tiles=None, stream_pass=None, stream_ranges=None, tag_words=None,
-             dedupe_variant=None, dedupe_limit=None, dedupe_bits=None, comm_self_loop=None, tag_pass=None, kway=None):
+             dedupe_variant=None, dedupe_limit=None, dedupe_bits=None, comm_self_loop=None, tag_pass=None, kway=None, tile_sort=None):
+        if tile_sort is not None:
+            self._check(self.lib.zk_tune(self.h, 19, int(tile_sort)))
         if kway is not None:
             self._check(self.lib.zk_tune(self.h, 18, int(kway)))
         if tag_pass is not None:
