@@ -366,8 +366,17 @@ def test_kmerize_early_collapse_paths_agree(ctx, K):
                 assert np.array_equal(k.to_host(), want["kmers"]), (name, on, packed)
                 assert np.array_equal(c.to_host(), want["counts"]), (name, on, packed)
                 assert list(st.acgt) == want["acgt"] and st.n_unique == len(want["kmers"])
+            # reads that do not repeat (and the mirrored pairs of K >= 28) finish their sort tile by tile in LDS (tilesort.hip): the
+            # same arrays without it, and the counted canonical list both ways
+            for ts in (0, 1):
+                ctx.tune(early_collapse=1, packed_pairs=1, tile_sort=ts)
+                k, c, st = ctx.kmerize(d, K)
+                assert np.array_equal(k.to_host(), want["kmers"]) and np.array_equal(c.to_host(), want["counts"]), (name, "tile_sort", ts)
+                ck, cc, _ = ctx.kmerize(d, K, native.KMERIZE_CANONICAL_ONLY)
+                ek, ec = ctx.mirror_expand(ck, cc, K)
+                assert np.array_equal(ek.to_host(), want["kmers"]) and np.array_equal(ec.to_host(), want["counts"]), (name, "canonical", ts)
         finally:
-            ctx.tune(early_collapse=1, packed_pairs=1)
+            ctx.tune(early_collapse=1, packed_pairs=1, tile_sort=1)
 
 
 @pytest.mark.parametrize("K", [16, 20, 25, 27])

@@ -192,6 +192,9 @@ int stream_pass1(zk_ctx* c, const u32* tags, const u16* dig, uint64_t n, const u
 // tilesort.hip: the lower bits of a sort, tile by tile in LDS
 int tile_sort_top_bits(uint64_t n, int key_bits, int rbits);   // the top bits the LSD passes must have sorted first (0 = not worth it)
 int tile_sort(zk_ctx* c, u64* keys, u32* vals, uint64_t n, int key_bits, int top, bool* declined);   // in place
+// ... and run-length counted in the same kernel: the distinct keys and their counts (uniq may be keys)
+int tile_sort_count(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int top, u64* uniq, u32* counts, uint64_t cap, uint64_t* n_unique,
+                    bool* declined);
 // select.hip
 int trim(zk_ctx* c, const u64* keys, const void* cnts, int cbits, uint64_t n, u64 lo, u64 hi, u64* ok, void* oc,
          uint64_t cap, uint64_t* n_out);

@@ -311,7 +311,9 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     uint64_t n = 0;
     u64* sorted = nullptr;
     bool presampled = false;
-    int tile_top = 0;          // > 0: LSD passes over these top bits only, then tile_sort
+    int tile_top = 0;          // > 0: LSD passes over these top bits only, then tile_sort_count
+    bool tile_counted = false; // ... which has counted the keys as well (tile_uc distinct ones)
+    uint64_t tile_uc = 0;
     StreamTags stags;          // set when the last pass wrote 32-bit tags instead of keys (`sorted` is then a u32 array)
     if (dedupe_bit) {
         // Sorting the top bits first only pays if the blocks can then be counted; an input that does not repeat its k-mers would
@@ -356,11 +358,16 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
     if (!dedupe_bit && tile_top) {
         src.lo_bit = 2 * K - tile_top; src.hi_bit = 0;
         if (!top_sorted) ZK_TRY(sort_stream(c, src, buf_a, buf_b, cap_keys, &n, st->acgt, &sorted));
+        // ... and counted there: the distinct k-mers leave the tiles with their counts -- straight into the caller's arrays when the
+        // canonical list is all that is wanted (the batches of library/engine.py), else over the keys, counts in the other buffer
         bool declined = false;
-        ZK_TRY(tile_sort(c, sorted, nullptr, n, 2 * K, tile_top, &declined));
+        u64* other = (sorted == buf_a) ? buf_b : buf_a;
+        if (canonical_only) ZK_TRY(tile_sort_count(c, sorted, n, 2 * K, tile_top, out_k, out_c, cap, &tile_uc, &declined));
+        else ZK_TRY(tile_sort_count(c, sorted, n, 2 * K, tile_top, sorted, (u32*)other, n, &tile_uc, &declined));
+        tile_counted = !declined;
         if (declined) {          // a block of equal top bits too long for a tile: every bit by passes, from where the keys are now
             u64* res = nullptr;
-            ZK_TRY(sort_keys_upper(c, sorted, sorted == buf_a ? buf_b : buf_a, n, 2 * K, 0, &res, ZK_PROF_PASS_KEYS));
+            ZK_TRY(sort_keys_upper(c, sorted, other, n, 2 * K, 0, &res, ZK_PROF_PASS_KEYS));
             sorted = res;
         }
         fused_bit = 0;
@@ -517,14 +524,20 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
             collapse_bit = 0;
         }
     }
-    if (!in_aux) ZK_TRY(rle(c, sorted, n, sorted, cnt, n, &uc));     // in place: sorted[0..uc) = distinct canonical k-mers
+    // the caller wants the counted canonical list itself (multi-GPU: it is exchanged before the strands are rebuilt): counted into
+    // the caller's arrays where the count is still to be taken
+    bool direct = false;
+    if (tile_counted) { uc = tile_uc; direct = canonical_only; }
+    else if (!in_aux && canonical_only) { ZK_TRY(rle(c, sorted, n, out_k, out_c, cap, &uc)); direct = true; }
+    else if (!in_aux) ZK_TRY(rle(c, sorted, n, sorted, cnt, n, &uc));     // in place: sorted[0..uc) = distinct canonical k-mers
     st->n_canonical = uc;
     if (uc == 0) return ZK_OK;
     if (canonical_only) {
-        // the caller wants the counted canonical list itself (multi-GPU: it is exchanged before the strands are rebuilt)
         if (uc > cap) return fail(c, ZK_ENOSPC, "output holds %llu entries, the batch has %llu distinct canonical k-mers", (unsigned long long)cap, (unsigned long long)uc);
-        ZK_HIP(c, hipMemcpyAsync(out_k, sorted, 8 * uc, hipMemcpyDeviceToDevice, c->stream));
-        ZK_HIP(c, hipMemcpyAsync(out_c, cnt, 4 * uc, hipMemcpyDeviceToDevice, c->stream));
+        if (!direct) {
+            ZK_HIP(c, hipMemcpyAsync(out_k, sorted, 8 * uc, hipMemcpyDeviceToDevice, c->stream));
+            ZK_HIP(c, hipMemcpyAsync(out_c, cnt, 4 * uc, hipMemcpyDeviceToDevice, c->stream));
+        }
         *n_out = uc;
         return ZK_OK;
     }
