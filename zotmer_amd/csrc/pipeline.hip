@@ -280,9 +280,35 @@ int mirror_expand(zk_ctx* c, const u64* ck, const u32* cc, uint64_t n, int K, u6
 // for any input: collapsing adjacent equal keys and summing equal keys later never loses or invents a count; the data
 // only decides how much is saved.  Whether it pays is read off a sample of the partially sorted array (its head holds a
 // random subset of the k-mers with all their copies); with little duplication the keys finish the sort as before.
+// replan (or null): set to 1, with nothing sorted yet, when the look before the sort says that the reads do not repeat their k-mers
+// and both strands are wanted -- then sorting the keys of BOTH strands (twice the keys through three passes and the tile sort, which
+// also counts) is less work than the canonical keys, their mirrored list and the union of the two; the caller makes room and calls
+// again with both_tiles.  both_tiles: `both`, by the tile-sort plan.
 static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bool both, u64* buf_a, u64* buf_b, uint64_t cap_keys,
-                        u64* out_k, u32* out_c, uint64_t cap, zk_kmerize_stats* st, uint64_t* n_out, bool canonical_only = false) {
+                        u64* out_k, u32* out_c, uint64_t cap, zk_kmerize_stats* st, uint64_t* n_out, bool canonical_only = false,
+                        int* replan = nullptr, bool both_tiles = false) {
     StreamSrc src{stream, n_bytes, K, both ? ZK_KEYS_BOTH : ZK_KEYS_CANONICAL, 0};
+    if (both && both_tiles) {
+        const int tt = tile_sort_top_bits(2 * n_bytes, 2 * K, sort_rbits(c));
+        if (tt) {
+            uint64_t n = 0;
+            u64* sorted = nullptr;
+            src.lo_bit = 2 * K - tt;
+            ZK_TRY(sort_stream(c, src, buf_a, buf_b, cap_keys, &n, st->acgt, &sorted));
+            st->n_windows = n / 2;
+            st->n_instances = n;
+            *n_out = 0;
+            bool declined = false;
+            ZK_TRY(tile_sort_count(c, sorted, n, 2 * K, tt, out_k, out_c, cap, n_out, &declined));
+            if (declined) {
+                u64* res = nullptr;
+                ZK_TRY(sort_keys_upper(c, sorted, sorted == buf_a ? buf_b : buf_a, n, 2 * K, 0, &res, ZK_PROF_PASS_KEYS));
+                ZK_TRY(rle(c, res, n, out_k, out_c, cap, n_out));
+            }
+            st->n_canonical = (K & 1) ? *n_out / 2 : 0;          // (odd K: no k-mer is its own reverse complement, the table is two lists of equal length)
+            return ZK_OK;
+        }
+    }
     // low bits to sort before looking for runs: 2^b >= 8 x keys, a whole number of passes, and at least one pass left over
     int collapse_bit = 0;
     int fused_bit = 0;            // > 0: the low passes stop here; the next digit is ranked tile by tile and counted by collapse_kernel
@@ -327,6 +353,7 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
         if (rc < 0) return rc;
         src.sample = nullptr;
         src.tags = nullptr;
+        if (rc == 1 && replan && !canonical_only && c->tile_sort && tile_sort_top_bits(2 * n_bytes, 2 * K, rb)) { *replan = 1; return ZK_OK; }
         if (rc == 1) {
             dedupe_bit = 0; src.lo_bit = 0;
             // the input does not repeat its k-mers: no collapse will pay either, every key goes to the end of the sort -- the top bits
@@ -655,7 +682,29 @@ int kmerize(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int flags, dou
             if (rc == 1) st->n_canonical = 0;      // side list overflowed: do it the long way
         }
     }
-    if (rc == 1) ZK_TRY(kmerize_full(c, stream, n_bytes, K, both, buf_a, buf_b, cap_keys, out_k, out_c, cap, st, &n_out, canonical_only));
+    if (rc == 1) {
+        // Reads that do not repeat their k-mers (the look before the sort says so), both strands wanted: the sort is planned again
+        // for the keys of both strands, if the device has the room (twice the sort buffers; the mirror's buffers are not needed then)
+        int replan = 0;
+        size_t mfree = 0, mtotal = 0;
+        const uint64_t need2 = 32 * n_bytes + slack + 2 * n_bytes / 16;
+        const bool may = !both && !canonical_only && c->tile_sort && hipMemGetInfo(&mfree, &mtotal) == hipSuccess &&
+                         (double)need2 < 0.9 * (double)(mfree + c->arena_size + c->aux_size);
+        ZK_TRY(kmerize_full(c, stream, n_bytes, K, both, buf_a, buf_b, cap_keys, out_k, out_c, cap, st, &n_out, canonical_only, may ? &replan : nullptr));
+        if (replan) {
+            arena_reset(c);
+            if (need2 > c->arena_size && (double)need2 >= 0.9 * (double)(mfree + c->arena_size) && c->aux) {
+                ZK_HIP(c, hipStreamSynchronize(c->stream));
+                ZK_HIP(c, hipFree(c->aux));
+                c->aux = nullptr; c->aux_size = 0;
+            }
+            ZK_TRY(arena_require(c, need2, need2));
+            const uint64_t cap2 = 2 * n_bytes;
+            ZK_TRY(arena_alloc(c, 8 * cap2, (void**)&buf_a));
+            ZK_TRY(arena_alloc(c, 8 * cap2, (void**)&buf_b));
+            ZK_TRY(kmerize_full(c, stream, n_bytes, K, true, buf_a, buf_b, cap2, out_k, out_c, cap, st, &n_out, false, nullptr, true));
+        }
+    }
     if (flags & ZK_KMERIZE_SUBSAMPLE) {
         uint64_t kept = 0;
         ZK_TRY(subsample_pairs(c, out_k, out_c, n_out, seed, p, &kept));

@@ -85,6 +85,9 @@ struct SortArgs {
     // outputs
     u64* kout;
     u32* vout;
+#ifdef ZK_PHASES
+    int dbg_local;      // measurement (ZK_LOCAL_PASS=1): a tile's keys go to the tile's own place, grouped by digit -- no offsets waited for
+#endif
     int tags_out;       // pipeline, array source: the pass writes only the low 32 bits of a key, as a u32 array at kout (the last pass
                         // before the block dedupe: the bits above are the block's number, which the key's place says)
     // digit of this pass
@@ -1644,6 +1647,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                     const u64* q = a.status + (u64)tileA * RADIX + d;
                     u64 w = vB ? rowA[j] : ld_agent(q);
                     int spins = 0;
+#ifdef ZK_PHASES
+                    if (a.dbg_local) w = st_pack(ZK_ST_INCLUSIVE, a.epoch, 0);
+#endif
                     while (st_state(w, a.epoch) == 0) {
                         if (++spins > ZK_SPIN_LIMIT) { atomicOr(a.err, ZK_DERR_SPIN_TIMEOUT | (32u << 8)); sm.abort = 1; break; }
                         __builtin_amdgcn_s_sleep(1);
@@ -1653,6 +1659,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                     if (PSTAT(tileA)) *PSTAT(tileA) = (1ull << 32) | (u32)spins;
 #endif
                     sm.gbase[d] = a.ghist[d] + (w & ZK_ST_VALUE_MASK) - dexA[j];
+#ifdef ZK_PHASES
+                    if (a.dbg_local) sm.gbase[d] = (u64)tileA * TILE;
+#endif
                 }
             }
             PSTAMP(tileA, 5);
@@ -2063,7 +2072,13 @@ struct Sorter {
             a.kin = in; a.kout = out; a.shift = plan.shift[p]; a.bits = plan.bits[p];
             a.ghist = ghist + p * C::RADIX;
             a.tags_out = (tags && p == plan.passes - 1) ? 1 : 0;
+#ifdef ZK_PHASES
+            if (const char* e = getenv("ZK_LOCAL_PASS")) a.dbg_local = atoi(e);
+#endif
             ZK_TRY(launch_keys_pass(c, a));
+#ifdef ZK_PHASES
+            if (a.dbg_local) { *n_keys = 0; return ZK_OK; }          // (nothing is where it belongs: nothing may be counted from it)
+#endif
             if (a.tags_out) {
                 const u32 tile = keys_pass_tile(c, n), tiles = (u32)div_up(n, tile);
                 const uint64_t blocks = 1ull << (plan.bits[0] + plan.bits[1]);

@@ -149,7 +149,8 @@ class KmerTable:
 
     Every batch is sorted and counted (zk_kmerize) straight into the top of the table slab; the tables sit on a stack and
     are union-summed pairwise like a binary counter (two tables of the same level make one of the next): the union goes to
-    a scratch slab sized for exactly |A u B| (|A n B| is one cheap intersect pass) and is copied back over its inputs.  So
+    a scratch slab sized for exactly |A u B| (|A n B| is one cheap intersect pass, skipped when the slab holds |A| + |B| anyway)
+    and is copied back over its inputs.  So
     n batches cost O(n log n) table traffic, steady state allocates nothing, and peak memory is the live tables plus one
     merge output.  The final arrays do not depend on where the batches are cut (the reference's -m 1 run, tests/golden)."""
 
@@ -259,7 +260,8 @@ class KmerTable:
         ak, ac = slab.k.view(na, oa), slab.c.view(na, oa)
         bk, bc = slab.k.view(nb, ob), slab.c.view(nb, ob)
         n_out = na + nb
-        if n_out >= self.EXACT_FROM:
+        # ... unless the scratch slab holds |A| + |B| entries as it is: the exact size could only save memory that is already there
+        if n_out >= self.EXACT_FROM and scratch.E < n_out:
             with _Phase(ctx, "intersect (size the union)"):
                 n_out -= ctx.split(ak, bk)[0]
         # The two tables at the bottom of the stack (the big merges): the union is not copied back -- the two slabs change
