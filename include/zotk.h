@@ -80,8 +80,10 @@ int zk_upload_async(zk_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
                                   * out of LDS (stream_pass.hip); 3 = the same, a tile's units leaving in two bursts (measurements; 2 is accepted and
                                   * equals 1); 0 = the look-back pipeline.  Other values are refused */
 #define ZK_TUNE_STREAM_RANGES 11 /* ... the number of ranges the stream is cut into, one workgroup each (0 = two per CU, the default; <= 4096) */
-#define ZK_TUNE_TAG_WORDS 12     /* zk_kmerize: 1 (default) = the pass before the block dedupe writes 32-bit tags instead of whole keys when the key bits
-                                  * below the blocks fit (K <= 25 after two passes); 0 = whole keys */
+#define ZK_TUNE_TAG_WORDS 12     /* zk_kmerize: 1 = the pass before the block dedupe writes 32-bit tags instead of whole keys when the key bits
+                                  * below the blocks fit (K <= 25 after two passes); 2 (default) = ... and ranks the keys of a tile by LDS adds
+                                  * where the tile lies inside one bucket of the pass before (nobody needs the order inside a block);
+                                  * 0 = whole keys */
 #define ZK_TUNE_DEDUPE_VARIANT 13 /* the block dedupe of zk_kmerize at <= 32 key bits below the blocks: 0 (default) = dedupe2_kernel, two 512-thread
                                   * workgroups per CU; 1 / 2 = one / two compare-and-swaps in flight per thread instead of four;
                                   * -1 = dedupe_kernel alone (one workgroup per CU, the table of rounds 2 and 3) */

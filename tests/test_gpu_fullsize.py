@@ -20,6 +20,12 @@ def ctx():
     c.close()
 
 
+def ctx_tag_words(ctx):
+    """the library's default for ZK_TUNE_TAG_WORDS (1: the tag pass ranks by ballots, 2: by LDS adds inside a bucket); the other one is
+    the variant the full-size test also runs"""
+    return native.DEFAULT_TAG_WORDS
+
+
 def revcomp(K, x):
     r = 0
     for _ in range(K):
@@ -65,13 +71,13 @@ def test_config2_full_size(ctx):
         ctx.tune(stream_pass=1)
     # ... from the second pass over static segments (tag_pass.hip; pass 0 then writes two arrays), and from the block dedupe with
     # one workgroup per CU (round 3's kernel; the default, dedupe2_kernel, made the first result)
-    for knob in (dict(tag_pass=1), dict(dedupe_variant=-1)):
+    for knob in (dict(tag_pass=1), dict(dedupe_variant=-1), dict(tag_words=3 - ctx_tag_words(ctx))):
         try:
             ctx.tune(**knob)
             k0, c0, _ = ctx.kmerize(d, K, out=out)
             assert k0.n == n_first and ctx.checksum(k0, c0) == want and ctx.first_descent(k0) == k0.n, knob
         finally:
-            ctx.tune(tag_pass=0, dedupe_variant=0)
+            ctx.tune(tag_pass=0, dedupe_variant=0, tag_words=ctx_tag_words(ctx))
     del k0, c0, k, c, out, d
     ctx.release_workspace()
 

@@ -402,15 +402,17 @@ def test_kmerize_forced_block_dedupe(ctx, K):
             want = zo.kmerize(K, reads)
             d = ctx.upload_stream(stream_of(reads))
             # tag_pass: the tags written by tag_pass.hip's pass over static segments (pass 0 leaves two arrays), or by the look-back pipeline
+            # tag_words 2: ... which takes the places inside a digit's run from LDS adds wherever a tile holds keys of one bucket only
+            # (big_block: nine such tiles)
             for tag_words, variant, limit, tag_pass in ((1, 0, 65536, 1), (1, 0, 65536, 0), (0, 0, 65536, 1), (1, 2, 65536, 1), (1, -1, 65536, 0),
-                                                       (1, -1, 65536, 1), (1, 0, 6, 1), (0, 2, 6, 0)):
+                                                       (1, -1, 65536, 1), (1, 0, 6, 1), (0, 2, 6, 0), (2, 0, 65536, 0), (2, -1, 65536, 0)):
                 ctx.tune(dedupe_bits=18, tag_words=tag_words, dedupe_variant=variant, dedupe_limit=limit, tag_pass=tag_pass)
                 k, c, st = ctx.kmerize(d, K)
                 assert np.array_equal(k.to_host(), want["kmers"]), (name, tag_words, variant, limit, tag_pass)
                 assert np.array_equal(c.to_host(), want["counts"]), (name, tag_words, variant, limit, tag_pass)
                 assert list(st.acgt) == want["acgt"] and st.n_unique == len(want["kmers"])
     finally:
-        ctx.tune(dedupe_bits=0, tag_words=1, dedupe_variant=0, dedupe_limit=65536, tag_pass=0)
+        ctx.tune(dedupe_bits=0, tag_words=native.DEFAULT_TAG_WORDS, dedupe_variant=0, dedupe_limit=65536, tag_pass=0)
 
 
 @pytest.mark.parametrize("K", [4, 12, 24, 25, 31, 32])

@@ -165,7 +165,7 @@ int zk_sort_keys(zk_ctx* c, uint64_t* d_keys, uint64_t n, int key_bits) {
     ZK_ARGS(c, key_bits >= 1 && key_bits <= 64);
     if (n == 0) return ZK_OK;
     arena_reset(c);
-    ZK_TRY(arena_require(c, 8 * n + (1 << 20), 8 * n + (1 << 20)));
+    ZK_TRY(arena_require(c, 8 * n + n / 64 + (1 << 20), 8 * n + n / 64 + (1 << 20)));          // (+ histograms, the tile sort's bounds)
     u64 *alt, *res;
     ZK_TRY(arena_alloc(c, 8 * n, (void**)&alt));
     ZK_TRY(sort_keys(c, (u64*)d_keys, alt, n, key_bits, &res));
@@ -178,7 +178,7 @@ int zk_sort_pairs(zk_ctx* c, uint64_t* d_keys, uint32_t* d_vals, uint64_t n, int
     ZK_ARGS(c, key_bits >= 1 && key_bits <= 64);
     if (n == 0) return ZK_OK;
     arena_reset(c);
-    ZK_TRY(arena_require(c, 12 * n + (1 << 20), 12 * n + (1 << 20)));
+    ZK_TRY(arena_require(c, 12 * n + n / 64 + (1 << 20), 12 * n + n / 64 + (1 << 20)));
     u64 *alt, *rk; u32 *valt, *rv;
     ZK_TRY(arena_alloc(c, 8 * n, (void**)&alt));
     ZK_TRY(arena_alloc(c, 4 * n, (void**)&valt));

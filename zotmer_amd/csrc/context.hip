@@ -329,7 +329,7 @@ int zk_tune(zk_ctx* c, int what, int value) {
 #endif
         return ZK_OK;
     }
-    if (what == ZK_TUNE_TAG_WORDS) { c->tag_words = value ? 1 : 0; return ZK_OK; }
+    if (what == ZK_TUNE_TAG_WORDS) { c->tag_words = value < 0 ? 0 : (value > 2 ? 2 : value); return ZK_OK; }
     if (what == ZK_TUNE_DEDUPE_VARIANT) { c->dedupe_variant = value < 0 ? -1 : (value & 3); return ZK_OK; }
     if (what == ZK_TUNE_KWAY) { c->kway = value < 0 ? 0 : (value > 2 ? 2 : value); return ZK_OK; }
     if (what == ZK_TUNE_TILE_SORT) { c->tile_sort = value ? 1 : 0; return ZK_OK; }

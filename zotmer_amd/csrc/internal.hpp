@@ -28,8 +28,10 @@ struct zk_ctx {
     int pairs_variant = 2;     // ... for (key, u32) pairs
     int stream_pass = 1;       // the first sort pass (from the base stream): 1 = static ranges, whole 64-byte units written from LDS
                                // (stream_pass.hip; 3 = a tile's units leave in two bursts, for measurements), 0 = the look-back pipeline
-    int tag_words = 1;         // zk_kmerize, block dedupe after two passes with at most 32 key bits below the blocks: the second pass writes
-                               // only those bits, as 32-bit tags (radix_sort.hip); 0 = whole keys
+    int tag_words = 2;         // zk_kmerize, block dedupe after two passes with at most 32 key bits below the blocks: the second pass writes
+                               // only those bits, as 32-bit tags (radix_sort.hip); 2 (default) = ... and takes a key's place in its digit's run
+                               // from a returning LDS add wherever a tile holds keys of one bucket of the pass before (pass_pipe_kernel VAR 3:
+                               // 23.6-24.0 against 24.7 ms); 1 = tags, every tile ranked by ballots; 0 = whole keys
     int dedupe_variant = 0;    // block dedupe at <= 32 tag bits: dedupe2_kernel's variant (dedupe2.hip), -1 = dedupe_kernel alone
     int dedupe_limit = 65536;  // ... blocks of this many keys or more go to dedupe_kernel (16-bit counts in dedupe2_kernel's table)
     int tag_pass = 0;          // ... 1 = the pass that writes them is tag_pass.hip's count / scan / scatter over static segments, reading pass 0's

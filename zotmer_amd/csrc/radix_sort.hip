@@ -88,6 +88,7 @@ struct SortArgs {
 #ifdef ZK_PHASES
     int dbg_local;      // measurement (ZK_LOCAL_PASS=1): a tile's keys go to the tile's own place, grouped by digit -- no offsets waited for
 #endif
+    const u32* straddle; // pipeline, VAR 3: one bit per tile of this pass's input, set where a bucket of the pass before begins inside the tile
     int tags_out;       // pipeline, array source: the pass writes only the low 32 bits of a key, as a u32 array at kout (the last pass
                         // before the block dedupe: the bits above are the block's number, which the key's place says)
     // digit of this pass
@@ -1383,9 +1384,15 @@ struct PipeSmem {
 
 // VAR: 1 only names the instantiation = the upper-bit passes over collapsed lists of packed words, so that a profiler lists them
 // apart from the dominant full-size passes (same code); 2 = the pass stores the keys' low 32 bits only (SortArgs::tags_out).
+// 3 = 2, and the keys of a tile take their places in their digit's run from a returning LDS add instead of the ballots: the pass
+// before the block dedupe is the last one, nobody looks at the order inside a block -- all that must survive is that a block's keys
+// stay together, i.e. the order of the BUCKETS of the pass before.  A tile that lies inside one such bucket (all but one in 1500 at
+// config 2's size) has nothing to keep; a tile in which a bucket begins (SortArgs::straddle) is ranked by the ballots as before.
 template <class C, int SRC, int VAR = 0>
 __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a, u32 tiles) {
     constexpr int BLOCK = C::BLOCK, ITEMS = C::ITEMS, RADIX = C::RADIX, NW = C::NW, DPT = C::DPT, TILE = C::TILE;
+    constexpr bool ATOM = VAR == 3, TAGS = VAR == 2 || VAR == 3;
+    static_assert(!ATOM || (SRC == SRC_ARRAY && NW >= 2), "the counters of the adds are the first two rows of the per-wave counters");
     static_assert(C::ROUNDS == 1, "the pipeline parks a whole tile in LDS");
     constexpr int NS = RADIX / 64;          // scanner workgroups: 64 digits each
     __shared__ PipeSmem<C> sm;
@@ -1404,6 +1411,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
     // Scanners hold the oldest tickets of the launch, hence they are resident, and every count they wait
     // for is published by a workgroup that holds a ticket.
     if (tid == 0) sm.abort = 0;
+    u32* cnt32 = reinterpret_cast<u32*>(&sm.cnt[0][0]);          // VAR 3: one counter per digit for the whole workgroup
+    if (ATOM && tid < RADIX) cnt32[tid] = 0;
+    bool dirty = false;          // ... a tile ranked by the ballots has left its per-wave counts there
     const u32 first = take_ticket(a.ticket, &sm.ticket) - a.ticket_base;
     if (first < (u32)NS) {
         constexpr int U = 32;
@@ -1507,6 +1517,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
         u32 live = 0;
         u32 tC = 0;
         bool vC = false;
+        bool atomB = false;          // VAR 3: tile B lies inside one bucket of the pass before: places from LDS adds
         bool early = false;          // the next tile's keys were asked for before tile A's stores
         u32 tcB[DPT], dexB[DPT];
         u32 incB = 0, tsumB = 0;
@@ -1557,6 +1568,24 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
             }
             // (Pass 0 has no order to keep, so its ranks could come from a returning LDS add per key instead of the ballots: measured,
             // 32.7 vs 30.9 ms.)
+            if constexpr (ATOM) atomB = !((a.straddle[tB >> 5] >> (tB & 31u)) & 1u);
+            if (ATOM && atomB) {
+                if (dirty) {          // (the tile before was ranked by the ballots and is being parked with those counts)
+                    __syncthreads();
+                    if (tid < RADIX) cnt32[tid] = 0;
+                    __syncthreads();
+                    dirty = false;
+                }
+                PSTAMP(tB, 1);
+#pragma unroll
+                for (int i = 0; i < ITEMS; i++) {
+                    const bool lv = (live >> i) & 1u;
+                    const u32 d = (u32)(key[i] >> a.shift) & dmask;
+                    const u32 r = lv ? atomicAdd(&cnt32[d], 1u) : 0u;
+                    if (i & 1) rank2[i / 2] |= r << 16; else rank2[i / 2] = r;
+                }
+            } else {
+            if constexpr (ATOM) dirty = true;
             // this wave's counters: private to the wave until the scan, so no barrier after zeroing them
             {
                 u32 z = 0;          // made here, not kept: a zero quad held (or spilled) across the tile loop costs four registers
@@ -1579,6 +1608,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                 const u32 pre = lv ? (u32)mycnt[d] : 0u;
                 if (i & 1) rank2[i / 2] |= (pre + below) << 16; else rank2[i / 2] = pre + below;
                 if (lv && below == npeer - 1) mycnt[d] = (u16)(pre + npeer);
+            }
             }
             PSTAMP(tB, 2);
             // the digits are recomputed when the tile is parked (two instructions each) instead of sixteen more registers
@@ -1619,6 +1649,9 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
             for (int j = 0; j < DPT; j++) {
                 const int d = tid * DPT + j;
                 u32 acc = 0;
+                if (ATOM && atomB) {
+                    if (d < RADIX) { acc = cnt32[d]; cnt32[d] = 0; }          // (zero again for the next tile: nobody reads it before the barriers below)
+                } else
                 if (d < RADIX) {
 #pragma unroll
                     for (int w = 0; w < NW; w++) {
@@ -1705,7 +1738,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
 #pragma unroll
                 for (int g = 0; g < G; g++)
                     if (slot0 + (i0 + g) * BLOCK < totalA) {
-                        if constexpr (VAR == 2) reinterpret_cast<u32*>(a.kout)[pos[g]] = (u32)kk[g];
+                        if constexpr (TAGS) reinterpret_cast<u32*>(a.kout)[pos[g]] = (u32)kk[g];
                         else a.kout[pos[g]] = kk[g];
                     }
             }
@@ -1719,7 +1752,8 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
             const u32 d = (u32)(key[i] >> a.shift) & dmask;
-            if ((live >> i) & 1u) sm.exch[sm.digit_off[d] + sm.cnt[wave][d] + ((rank2[i / 2] >> (16 * (i & 1))) & 0xffffu)] = key[i];
+            const u32 inwave = (ATOM && atomB) ? 0u : (u32)sm.cnt[wave][d];
+            if ((live >> i) & 1u) sm.exch[sm.digit_off[d] + inwave + ((rank2[i / 2] >> (16 * (i & 1))) & 0xffffu)] = key[i];
         }
         tileA = tB;
         totalA = sm.total_live;
@@ -1751,6 +1785,15 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
             }
         }
     }
+}
+
+// starts[b] = where bucket b of the pass before begins in this pass's input: the tile it begins in (unless it begins at the tile's
+// first key) holds keys of two buckets or more
+__global__ void straddle_kernel(const u64* __restrict__ starts, u32 buckets, u32 tile, u32* __restrict__ bitmap) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0 || b >= buckets) return;
+    const u64 pos = starts[b];
+    if (pos % tile) atomicOr(&bitmap[(pos / tile) >> 5], 1u << ((pos / tile) & 31u));
 }
 
 // Where do the blocks of the block dedupe start when the last pass has written tags (no key to search for)?  Block (dh, v) --
@@ -1840,7 +1883,9 @@ struct Sorter {
         a.dbg2 = c->dbg ? c->dbg + 8ull * tiles : nullptr;
         prof_begin(c, SRC == SRC_STREAM ? ZK_PROF_PASS_STREAM : (a.prof_tag ? a.prof_tag : ZK_PROF_PASS_KEYS),
                    SRC == SRC_STREAM ? a.n_bytes + 8 * a.n : (a.tags_out ? 12 : 16) * a.n);
-        if (SRC == SRC_ARRAY && a.tags_out)
+        if (SRC == SRC_ARRAY && a.tags_out && a.straddle)
+            hipLaunchKernelGGL((pass_pipe_kernel<C, SRC_ARRAY, 3>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
+        else if (SRC == SRC_ARRAY && a.tags_out)
             hipLaunchKernelGGL((pass_pipe_kernel<C, SRC_ARRAY, 2>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
         else if (SRC == SRC_ARRAY && a.prof_tag == ZK_PROF_PASS_PACKED)
             hipLaunchKernelGGL((pass_pipe_kernel<C, SRC, 1>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
@@ -2072,6 +2117,18 @@ struct Sorter {
             a.kin = in; a.kout = out; a.shift = plan.shift[p]; a.bits = plan.bits[p];
             a.ghist = ghist + p * C::RADIX;
             a.tags_out = (tags && p == plan.passes - 1) ? 1 : 0;
+            a.straddle = nullptr;
+            if (a.tags_out && c->tag_words >= 2) {
+                // the tiles in which a bucket of the pass before begins keep their order (see pass_pipe_kernel, VAR 3): one bit each
+                const u32 tile = keys_pass_tile(c, n), tiles = (u32)div_up(n, tile);
+                u32* bm;
+                ZK_TRY(arena_alloc(c, sizeof(u32) * (tiles / 32 + 1), (void**)&bm));
+                ZK_HIP(c, hipMemsetAsync(bm, 0, sizeof(u32) * (tiles / 32 + 1), c->stream));
+                hipLaunchKernelGGL(straddle_kernel, dim3((C::RADIX + 255) / 256), dim3(256), 0, c->stream, (const u64*)(ghist + (p - 1) * C::RADIX),
+                                   1u << plan.bits[p - 1], tile, bm);
+                ZK_HIP(c, hipGetLastError());
+                a.straddle = bm;
+            }
 #ifdef ZK_PHASES
             if (const char* e = getenv("ZK_LOCAL_PASS")) a.dbg_local = atoi(e);
 #endif

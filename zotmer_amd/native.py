@@ -21,6 +21,7 @@ LIB_PATH = os.environ.get("ZOTK_LIB") or os.path.join(_HERE, "libzotk.so")
 
 ZK_OK, ZK_EINVAL, ZK_ENOMEM, ZK_EHIP, ZK_ENOSPC, ZK_EOVERFLOW, ZK_EINTERNAL, ZK_ERANGE = 0, -1, -2, -3, -4, -5, -6, -7
 KMERIZE_CANONICAL, KMERIZE_BOTH, KMERIZE_SUBSAMPLE, KMERIZE_CANONICAL_ONLY = 0, 1, 2, 4
+DEFAULT_TAG_WORDS = 2          # zk_tune(ZK_TUNE_TAG_WORDS) as the library starts (csrc/internal.hpp)
 
 _ERRNAMES = {-1: "ZK_EINVAL", -2: "ZK_ENOMEM", -3: "ZK_EHIP", -4: "ZK_ENOSPC", -5: "ZK_EOVERFLOW",
              -6: "ZK_EINTERNAL", -7: "ZK_ERANGE"}
