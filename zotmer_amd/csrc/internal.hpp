@@ -180,7 +180,8 @@ int collapse_pass(zk_ctx* c, const u64* keys, uint64_t n, int shift, int bits, i
 int sort_stream(zk_ctx* c, const StreamSrc& src, u64* buf_a, u64* buf_b, uint64_t cap, uint64_t* n_keys,
                 uint64_t acgt[4], u64** result);
 // stream_pass.hip: histogram + first pass over static stream ranges
-struct StreamRows { u32* rows = nullptr; u64* offs = nullptr; u32 ranges = 0, radix = 0; u32* gcodes = nullptr; u16* gvalid = nullptr; };
+struct StreamRows { u32* rows = nullptr; u64* offs = nullptr; u32 ranges = 0, radix = 0; u32* gcodes = nullptr; u16* gvalid = nullptr;
+                    u32 strands = 1; };          // 2 (ZK_KEYS_BOTH): rows [ranges + w] are the reverse strand of range w
 int stream_hist(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, const PassPlan& plan, u64* ghist, u32 gstride,
                 u64* d_acgt, u64* d_n, u64* rec_info, u64* sample, u32 sample_cap, int sample_shift, u64 sample_value, u32* sample_n,
                 void* image_room, uint64_t image_room_bytes, StreamRows* out);

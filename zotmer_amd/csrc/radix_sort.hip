@@ -2014,7 +2014,7 @@ struct Sorter {
         const u32 sample_cap = 1u << 20;
         const bool sampling = src.sample && cap >= 4ull * sample_cap && src.mode == ZK_KEYS_CANONICAL;
         // stream_pass.hip: the pass over static stream ranges needs the digit counts of pass 0 per range, from its own histogram kernel
-        const bool ranged = c->stream_pass && src.mode != ZK_KEYS_BOTH;
+        const bool ranged = c->stream_pass != 0;          // (ZK_KEYS_BOTH: the two strands of a range as two ranges)
         StreamRows srows;
         if (ranged) {
             u64* rec_info = c->d_scalars + 20;

@@ -162,6 +162,7 @@ struct SHistArgs {
     u32 sample_cap;
     int sample_shift;
     u64 sample_value;
+    u32 revbase;                  // ZK_KEYS_BOTH: where the bins of pass 0's digit of the reverse strand start in LDS (rows [ranges + w])
     u32 ranges, split;            // grid = ranges * split: workgroup (w, s) takes every split-th tile of range w
     u32* gcodes;                  // [ceil(n_bytes / 16)] the stream's 2-bit image, 16 bases per word (first base on top) ...
     u16* gvalid;                  // ... and which of them are bases: the pass reads these instead of encoding the bytes again
@@ -196,6 +197,9 @@ __global__ __launch_bounds__(SH_BLOCK, 4) void stream_hist_kernel(SHistArgs h) {
     const u64 mask = ~0ull >> (64 - 2 * K);
     const u32 mlo = (u32)mask, mhi = (u32)(mask >> 32);
     const bool canon = CANON_T == 1 ? true : h.mode == ZK_KEYS_CANONICAL;
+    // ZK_KEYS_BOTH: x and rc x are two keys.  The pass takes the two strands of a range as two ranges of their own (w: x, ranges + w:
+    // rc x), so pass 0's digit is counted apart for them; only the table-driven form (not TWO) knows this mode.
+    const bool both = CANON_T != 1 && h.mode == ZK_KEYS_BOTH;
     // TWO: the two digits
     const u32 sh0 = (u32)h.plan.shift[0] - (HI ? 32u : 0u), sh1 = (u32)h.plan.shift[1] - (HI ? 32u : 0u);
     const u32 dm0 = (1u << h.plan.bits[0]) - 1u, dm1 = (1u << h.plan.bits[1]) - 1u;
@@ -310,6 +314,13 @@ __global__ __launch_bounds__(SH_BLOCK, 4) void stream_hist_kernel(SHistArgs h) {
                 atomicAdd(&bins[base1 + ((u32)(kd >> sh1) & dm1)], inc);
             } else {
                 for (int p = 0; p < np; p++) atomicAdd(&bins[pbase[p] + ((u32)(kd >> pshift[p]) & pmask[p])], inc);
+                if (both) {
+                    typename std::conditional<HI, u32, u64>::type kr;
+                    if constexpr (HI) kr = ww.bhi(i) & mhi;
+                    else kr = ((u64)(ww.bhi(i) & mhi) << 32) | (ww.blo(i) & mlo);
+                    atomicAdd(&bins[h.revbase + ((u32)(kr >> pshift[0]) & pmask[0])], inc);
+                    for (int p = 1; p < np; p++) atomicAdd(&bins[pbase[p] + ((u32)(kr >> pshift[p]) & pmask[p])], inc);
+                }
             }
             if constexpr (HI) {
                 if (h.sample) hits |= ((kd >> ssh) == sval ? 1u : 0u) << (15 - i);          // looked at once per tile, below
@@ -338,6 +349,11 @@ __global__ __launch_bounds__(SH_BLOCK, 4) void stream_hist_kernel(SHistArgs h) {
         const u32 c = bins[i];
         if (!c) continue;
         if (i < r0) atomicAdd(&h.rows[(u64)w * r0 + i], c);
+        if (both && i >= h.revbase) {          // pass 0's digit, reverse strand
+            atomicAdd(&h.rows[(u64)(h.ranges + w) * r0 + (i - h.revbase)], c);
+            atomicAdd(&h.ghist[i - h.revbase], (u64)c);
+            continue;
+        }
         int p = 0;          // the pass bin i belongs to
         for (int q = 1; q < np; q++) if (i >= pbase[q]) p = q;
         atomicAdd(&h.ghist[(u64)p * h.gstride + (i - pbase[p])], (u64)c);
@@ -380,6 +396,7 @@ struct P0Args {
     u64 n_bytes;
     int K;
     StreamTiling tl;
+    u32 ranges;           // stream ranges; the grid is twice that for ZK_KEYS_BOTH: workgroup ranges + w writes the reverse strand of range w
     int by_record;        // the host has seen the histogram kernel's verdict: threads follow the records (else positions)
     int shift, bits;
     const u64* offs;      // [ranges][1 << bits]
@@ -447,9 +464,10 @@ __global__ __launch_bounds__(P0_BLOCK, 4) void stream_pass0_kernel(P0Args a) {
     static_assert(RADIX == BLOCK && (G & (G - 1)) == 0 && 64 % G == 0, "one digit per thread; whole units per wave instruction");
     __shared__ S sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const u32 w = blockIdx.x;
+    const u32 w = blockIdx.x;          // the row of offs / rows
+    const bool rev = !CANON && w >= a.ranges;          // (ZK_KEYS_BOTH: the second half of the grid)
     const u32 radix = 1u << a.bits;
-    const u64 B = (u64)w * a.tl.range_bytes;
+    const u64 B = (u64)(rev ? w - a.ranges : w) * a.tl.range_bytes;
     if (B >= a.n_bytes) return;
     const u64 E = (B + a.tl.range_bytes < a.n_bytes) ? B + a.tl.range_bytes : a.n_bytes;
     const u32 tile_bytes = a.by_record ? a.tl.tile_bytes : (u32)P0_TILE;
@@ -648,7 +666,10 @@ __global__ __launch_bounds__(P0_BLOCK, 4) void stream_pass0_kernel(P0Args a) {
                 if constexpr (CANON) {
                     const u64 xb = ((u64)(ww.bhi(i) & mhi) << 32) | (FAST ? ww.blo(i) : (ww.blo(i) & mlo));
                     key[i] = x < xb ? x : xb;
-                } else key[i] = x;
+                } else {
+                    const u64 xb = ((u64)(ww.bhi(i) & mhi) << 32) | (FAST ? ww.blo(i) : (ww.blo(i) & mlo));
+                    key[i] = rev ? xb : x;
+                }
             }
         }
         // ---- what the last tile left of this thread's digit: into registers, the park below moves it ----------
@@ -782,6 +803,10 @@ int stream_hist(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, 
     bool hi = 2 * K > 32;
     for (int p = 0; p < plan.passes; p++) { h.binbase[p] = nb; nb += 1u << plan.bits[p]; if (plan.shift[p] < 32) hi = false; }
     if (sample && sample_shift < 32) hi = false;
+    const bool both = mode == ZK_KEYS_BOTH;
+    const u32 strands = both ? 2u : 1u;
+    h.revbase = nb;
+    if (both) nb += 1u << plan.bits[0];
     h.nbins = nb;
     h.ghist = ghist; h.gstride = gstride;
     h.acgt = d_acgt; h.rec_info = rec_info;
@@ -795,8 +820,8 @@ int stream_hist(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, 
     const u32 r0 = 1u << plan.bits[0];
     const uint64_t nchunks = (n_bytes + 15) / 16;
     u32* rows; u64* offs;
-    ZK_TRY(arena_alloc(c, sizeof(u32) * (uint64_t)h.ranges * r0, (void**)&rows));
-    ZK_TRY(arena_alloc(c, sizeof(u64) * (uint64_t)h.ranges * r0, (void**)&offs));
+    ZK_TRY(arena_alloc(c, sizeof(u32) * (uint64_t)strands * h.ranges * r0, (void**)&rows));
+    ZK_TRY(arena_alloc(c, sizeof(u64) * (uint64_t)strands * h.ranges * r0, (void**)&offs));
     // the stream's 2-bit image (3/8 of the stream's size): in the room the caller has for it (the tail of the second sort buffer, idle
     // until pass 1), else from the arena
     const uint64_t codes_bytes = (sizeof(u32) * nchunks + 255) & ~255ull, image_bytes = codes_bytes + ((sizeof(u16) * nchunks + 255) & ~255ull);
@@ -805,12 +830,12 @@ int stream_hist(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, 
     else ZK_TRY(arena_alloc(c, image_bytes, (void**)&img));
     h.gcodes = (u32*)img; h.gvalid = (u16*)(img + codes_bytes);
     h.rows = rows;
-    ZK_HIP(c, hipMemsetAsync(rows, 0, sizeof(u32) * (uint64_t)h.ranges * r0, c->stream));
+    ZK_HIP(c, hipMemsetAsync(rows, 0, sizeof(u32) * (uint64_t)strands * h.ranges * r0, c->stream));
     ZK_HIP(c, hipMemsetAsync(ghist, 0, sizeof(u64) * MAX_PASSES * gstride, c->stream));
     if (d_acgt) ZK_HIP(c, hipMemsetAsync(d_acgt, 0, sizeof(u64) * 4, c->stream));
     const u32 grid = h.ranges * h.split;
     prof_begin(c, ZK_PROF_HIST_STREAM, n_bytes);
-    const bool two = plan.passes == 2;
+    const bool two = plan.passes == 2 && !both;
     if (hi && two && mode == ZK_KEYS_CANONICAL) hipLaunchKernelGGL((stream_hist_kernel<true, true, 1>), dim3(grid), dim3(SH_BLOCK), nb * sizeof(u32), c->stream, h);
     else if (hi && two) hipLaunchKernelGGL((stream_hist_kernel<true, true>), dim3(grid), dim3(SH_BLOCK), nb * sizeof(u32), c->stream, h);
     else if (hi) hipLaunchKernelGGL((stream_hist_kernel<true, false>), dim3(grid), dim3(SH_BLOCK), nb * sizeof(u32), c->stream, h);
@@ -818,7 +843,7 @@ int stream_hist(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, 
     else hipLaunchKernelGGL((stream_hist_kernel<false, false>), dim3(grid), dim3(SH_BLOCK), nb * sizeof(u32), c->stream, h);
     prof_end(c);
     ZK_HIP(c, hipGetLastError());
-    out->rows = rows; out->offs = offs; out->ranges = h.ranges; out->radix = r0; out->gcodes = h.gcodes; out->gvalid = h.gvalid;
+    out->rows = rows; out->offs = offs; out->ranges = h.ranges; out->strands = strands; out->radix = r0; out->gcodes = h.gcodes; out->gvalid = h.gvalid;
     return ZK_OK;
 }
 
@@ -826,10 +851,13 @@ int stream_hist(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, int mode, 
 int stream_pass0(zk_ctx* c, uint64_t n_bytes, int K, int mode, int shift, int bits, const u64* ghist0, const StreamRows& rows,
                  uint64_t first_nl, bool uniform, u64* kout, uint64_t n, int variant, const StreamPlanes* planes) {
     if (bits < 1 || bits > 9 || (1u << bits) != rows.radix) return fail(c, ZK_EINTERNAL, "stream_pass0: %d digit bits, rows of %u", bits, rows.radix);
-    hipLaunchKernelGGL(rows_scan_kernel, dim3((rows.radix + 255) / 256), dim3(256), 0, c->stream, rows.rows, ghist0, rows.ranges, rows.radix, rows.offs);
+    if ((mode == ZK_KEYS_BOTH) != (rows.strands == 2)) return fail(c, ZK_EINTERNAL, "stream_pass0: rows of %u strands for mode %d", rows.strands, mode);
+    const u32 grid = rows.ranges * rows.strands;
+    hipLaunchKernelGGL(rows_scan_kernel, dim3((rows.radix + 255) / 256), dim3(256), 0, c->stream, rows.rows, ghist0, grid, rows.radix, rows.offs);
     P0Args a = {};
     a.gcodes = rows.gcodes; a.gvalid = rows.gvalid; a.n_bytes = n_bytes; a.K = K;
     a.tl = make_tiling(n_bytes, first_nl, K, rows.ranges);
+    a.ranges = rows.ranges;
     a.by_record = (uniform && a.tl.rec) ? 1 : 0;
     a.shift = shift; a.bits = bits; a.offs = rows.offs; a.rows = rows.rows; a.kout = kout; a.n = n; a.err = c->d_err; a.dbg = c->dbg; a.dbg_mode = variant >> 8; a.split_stores = (variant & 0xff) == 3;          // measured: 10.05 vs 8.73 ms on 20 M reads -- the held-back half sits in the key phase's way
     const bool canon = mode == ZK_KEYS_CANONICAL, fast = 2 * K > 32 && shift >= 32;
@@ -844,10 +872,10 @@ int stream_pass0(zk_ctx* c, uint64_t n_bytes, int K, int mode, int shift, int bi
         return ZK_OK;
     }
     prof_begin(c, ZK_PROF_PASS_STREAM, n_bytes + 8 * n);
-    if (canon && fast) hipLaunchKernelGGL((stream_pass0_kernel<9, 8, true, true>), dim3(rows.ranges), dim3(P0_BLOCK), 0, c->stream, a);
-    else if (canon) hipLaunchKernelGGL((stream_pass0_kernel<9, 8, true, false>), dim3(rows.ranges), dim3(P0_BLOCK), 0, c->stream, a);
-    else if (fast) hipLaunchKernelGGL((stream_pass0_kernel<9, 8, false, true>), dim3(rows.ranges), dim3(P0_BLOCK), 0, c->stream, a);
-    else hipLaunchKernelGGL((stream_pass0_kernel<9, 8, false, false>), dim3(rows.ranges), dim3(P0_BLOCK), 0, c->stream, a);
+    if (canon && fast) hipLaunchKernelGGL((stream_pass0_kernel<9, 8, true, true>), dim3(grid), dim3(P0_BLOCK), 0, c->stream, a);
+    else if (canon) hipLaunchKernelGGL((stream_pass0_kernel<9, 8, true, false>), dim3(grid), dim3(P0_BLOCK), 0, c->stream, a);
+    else if (fast) hipLaunchKernelGGL((stream_pass0_kernel<9, 8, false, true>), dim3(grid), dim3(P0_BLOCK), 0, c->stream, a);
+    else hipLaunchKernelGGL((stream_pass0_kernel<9, 8, false, false>), dim3(grid), dim3(P0_BLOCK), 0, c->stream, a);
     prof_end(c);
     ZK_HIP(c, hipGetLastError());
     return ZK_OK;
