@@ -45,6 +45,7 @@ struct TileSortSmem {
     u32 wsum[TS_BLOCK / 64];
 };
 typedef TileSortSmem<14, 4096, false> TileSortKeys;
+constexpr int TS_COUNT_ITEMS = 12;          // the counting form holds a tile's entries in registers over the next tile's load: 12 a thread fit
 typedef TileSortSmem<10, 2048, true> TileSortPairs;
 
 struct TileSortArgs {
@@ -260,6 +261,40 @@ struct TileCountArgs {
     u64* dbg;                 // diagnostic build: where the phase sums go (else null)
 };
 
+// common.hpp's decoupled look-back in two steps, so that work can be put between them: a tile publishes its count as soon as it has
+// it (one thread), and finds the sum over the tiles before it later (one wave; publishes the inclusive prefix)
+__device__ __forceinline__ void lookback_publish(u64* status, u32 tile, u64 total, u32 epoch) {
+    st_agent(&status[tile], st_pack(tile == 0 ? ZK_ST_INCLUSIVE : ZK_ST_PARTIAL, epoch, total));
+}
+__device__ __forceinline__ u64 lookback_resolve(u64* status, u32 tile, u64 total, u32 epoch, u32* err) {
+    const int l = lane_id();
+    if (tile == 0) return 0;
+    u64 excl = 0;
+    long long idx = (long long)tile - 1 - l;   // lane 0 looks at the nearest predecessor
+    int spins = 0;
+    while (true) {
+        const u64 w = (idx >= 0) ? ld_agent(&status[idx]) : st_pack(ZK_ST_INCLUSIVE, epoch, 0);
+        const u64 s = st_state(w, epoch);
+        const u64 incl = __ballot(s == ZK_ST_INCLUSIVE);
+        const u64 empty = __ballot(s == 0);
+        const u64 need = incl ? ((incl & (0ull - incl)) - 1) | (incl & (0ull - incl)) : ~0ull;  // lanes <= first inclusive
+        if (empty & need) {
+            if (++spins > ZK_SPIN_LIMIT) {
+                if (l == 0) atomicOr(err, ZK_DERR_SPIN_TIMEOUT | (0x40u << 8));
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        const u64 take = ((need >> l) & 1ull) ? (w & ZK_ST_VALUE_MASK) : 0ull;
+        excl += wave_sum_u64(take);
+        if (incl) break;
+        idx -= 64;
+    }
+    if (l == 0) st_agent(&status[tile], st_pack(ZK_ST_INCLUSIVE, epoch, excl + total));
+    return excl;
+}
+
 template <int ITEMS, int G>
 __global__ __launch_bounds__(TS_BLOCK, 2 * TS_BLOCK / 256) void tile_sort_count_kernel(TileCountArgs a) {
     using S = TileSortSmem<ITEMS, G, false>;
@@ -277,6 +312,34 @@ __global__ __launch_bounds__(TS_BLOCK, 2 * TS_BLOCK / 256) void tile_sort_count_
     u32 ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ntile = 0;
     u32 tlast = a.dbg ? (u32)__builtin_amdgcn_s_memtime() : 0u;
     (void)tlast; (void)ph;
+    // A tile does not wait for its place among the distinct keys: it publishes its count, takes its (k-mer, count) entries into
+    // registers and goes on to load and group the next tile; only then does it look back -- by then the tiles before it, which run
+    // in step with it, have published theirs (waiting at once cost 29 % of a tile: every tile waited for the slowest of ~500).
+    u64 hk[ITEMS];          // the held tile's entries tid, tid + BLOCK, ...
+    u32 hc[ITEMS / 2];      // ... and their counts, two to a word
+    bool have = false;
+    u32 pt = 0, ptotal = 0;
+    auto resolve_and_write = [&](int tid) {
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        if (wave == 0) {
+            const u64 ex = lookback_resolve(a.status, pt, ptotal, a.epoch, a.err);
+            if (lane == 0) {
+                s_base = ex;
+                if (pt == a.tiles - 1) *a.d_total = ex + ptotal;
+                if (ex + ptotal > a.cap) atomicOr(a.err, ZK_DERR_CAPACITY);
+            }
+        }
+        __syncthreads();
+        const u64 base = s_base;
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            const u32 u = (u32)j * TS_BLOCK + tid;
+            if (u < ptotal && base + u < a.cap) {
+                a.uniq[base + u] = hk[j];
+                a.counts[base + u] = (hc[j / 2] >> (16 * (j & 1))) & 0xffffu;
+            }
+        }
+    };
     while (true) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
@@ -284,31 +347,34 @@ __global__ __launch_bounds__(TS_BLOCK, 2 * TS_BLOCK / 256) void tile_sort_count_
         const u32 t = take_ticket(a.ticket, &s_ticket) - a.ticket_base;          // (barrier inside)
         if (t >= a.tiles) break;
         const u64 lo = a.bounds[t], hi = a.bounds[t + 1];
-        const u32 m = (u32)(hi - lo);          // <= CAP: no flag; may be 0 (the look-back still wants this tile's word)
+        const u32 m = (u32)(hi - lo);          // 1 .. CAP: no block was too long
+        TS_PHASE(0);          // ticket
+        const TileMap tm = tile_group<ITEMS, G, false>(sm, a.kin, nullptr, lo, m, a.pshift, tid);
+        TS_PHASE(1);          // loaded and grouped
+        if (have) resolve_and_write(tid);          // the tile before: its place, its entries out of the registers
+        TS_PHASE(5);          // look-back of the tile before (wave 0), barrier, its stores issued
+        u64 mine[ITEMS];
+        u32 place[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; j += 2) {
+            u32 i[2] = {(u32)j * TS_BLOCK + tid, (u32)(j + 1) * TS_BLOCK + tid};
+            u64 mm[2];
+            u32 pp[2];
+            tile_rank<2, false>(sm, tm, i, m, mm, pp);
+            mine[j] = mm[0]; mine[j + 1] = mm[1];
+            place[j] = pp[0]; place[j + 1] = pp[1];
+        }
+        TS_PHASE(2);          // ranked
+        __syncthreads();          // every entry read: the tile goes back sorted
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++)
+            if ((u32)j * TS_BLOCK + tid < m) sm.keys[place[j]] = mine[j];
+        __syncthreads();
+        TS_PHASE(3);          // sorted in LDS
+        // heads: thread t looks at the ITEMS consecutive entries from t * ITEMS
         u32 total = 0;
-        if (m) {
-            TS_PHASE(0);          // ticket
-            const TileMap tm = tile_group<ITEMS, G, false>(sm, a.kin, nullptr, lo, m, a.pshift, tid);
-            TS_PHASE(1);          // loaded and grouped
-            u64 mine[ITEMS];
-            u32 place[ITEMS];
-#pragma unroll
-            for (int j = 0; j < ITEMS; j += 2) {
-                u32 i[2] = {(u32)j * TS_BLOCK + tid, (u32)(j + 1) * TS_BLOCK + tid};
-                u64 mm[2];
-                u32 pp[2];
-                tile_rank<2, false>(sm, tm, i, m, mm, pp);
-                mine[j] = mm[0]; mine[j + 1] = mm[1];
-                place[j] = pp[0]; place[j + 1] = pp[1];
-            }
-            TS_PHASE(2);          // ranked
-            __syncthreads();          // every entry read: the tile goes back sorted
-#pragma unroll
-            for (int j = 0; j < ITEMS; j++)
-                if ((u32)j * TS_BLOCK + tid < m) sm.keys[place[j]] = mine[j];
-            __syncthreads();
-            TS_PHASE(3);          // sorted in LDS
-            // heads: thread t looks at the ITEMS consecutive entries from t * ITEMS
+        u16* hp = reinterpret_cast<u16*>(sm.start);
+        {
             const u32 p0 = (u32)tid * ITEMS;
             u64 prev = p0 > 0 && p0 <= m ? sm.keys[p0 - 1] : 0ull;
             u32 hm = 0;
@@ -326,35 +392,28 @@ __global__ __launch_bounds__(TS_BLOCK, 2 * TS_BLOCK / 256) void tile_sort_count_
             u32 u = inc - nh;
 #pragma unroll
             for (int w = 0; w < NW; w++) { u += w < wave ? sm.wsum[w] : 0u; total += sm.wsum[w]; }
-            u16* hp = reinterpret_cast<u16*>(sm.start);
 #pragma unroll
             for (int j = 0; j < ITEMS; j++)
                 if ((hm >> j) & 1u) hp[u++] = (u16)(p0 + j);
             if (tid == 0) hp[total] = (u16)m;
-            TS_PHASE(4);          // heads
         }
-        if (wave == 0) {
-            const u64 ex = lookback_exclusive(a.status, t, total, a.epoch, a.err);
-            if (lane == 0) {
-                s_base = ex;
-                if (t == a.tiles - 1) *a.d_total = ex + total;
-                if (ex + total > a.cap) atomicOr(a.err, ZK_DERR_CAPACITY);
-            }
+        if (tid == 0) lookback_publish(a.status, t, total, a.epoch);
+        __syncthreads();          // the heads' places are there
+        TS_PHASE(4);          // heads
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            const u32 u = (u32)j * TS_BLOCK + tid;
+            const u32 p = hp[u < total ? u : 0u], q = hp[u < total ? u + 1 : 0u];
+            hk[j] = sm.keys[p];
+            const u32 len = (q - p) & 0xffffu;
+            if (j & 1) hc[j / 2] |= len << 16; else hc[j / 2] = len;
         }
-        __syncthreads();
-        TS_PHASE(5);          // look-back (wave 0), barrier
-        if (m) {
-            const u64 base = s_base;
-            const u16* hp = reinterpret_cast<const u16*>(sm.start);
-            for (u32 u = (u32)tid; u < total; u += TS_BLOCK) {
-                const u32 p = hp[u], len = (u32)hp[u + 1] - p;
-                if (base + u < a.cap) { a.uniq[base + u] = sm.keys[p]; a.counts[base + u] = len; }
-            }
-        }
+        have = true; pt = t; ptotal = total;
         __syncthreads();          // the tile's LDS (and the ticket word) are free again
-        TS_PHASE(6);          // written
+        TS_PHASE(6);          // entries taken
         ntile++;
     }
+    if (have) resolve_and_write(threadIdx.x);
     if (a.dbg && threadIdx.x == 0 && blockIdx.x < 256) {
         for (int k = 0; k < 8; k++) a.dbg[(u64)blockIdx.x * 16 + k] = ph[k];
         a.dbg[(u64)blockIdx.x * 16 + 8] = ntile;
@@ -415,7 +474,7 @@ int tile_sort_count(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int to
     *declined = false;
     *n_unique = 0;
     if (n == 0) return ZK_OK;
-    const u32 T = (u32)TileSortKeys::CAP - TS_SLACK;
+    const u32 T = (u32)TS_BLOCK * TS_COUNT_ITEMS - TS_SLACK;
     const uint64_t tiles64 = div_up(n, T);
     if (tiles64 >= (1ull << 31)) return fail(c, ZK_EINVAL, "tile sort: %llu keys", (unsigned long long)n);
     const u32 tiles = (u32)tiles64;
@@ -435,7 +494,7 @@ int tile_sort_count(zk_ctx* c, const u64* keys, uint64_t n, int key_bits, int to
     a.status = c->status; a.ticket = c->d_ticket; a.err = c->d_err; a.d_total = c->d_scalars + 9;
     a.dbg = c->dbg;
     prof_begin(c, ZK_PROF_TILE_SORT, 8 * n);
-    hipLaunchKernelGGL((tile_sort_count_kernel<14, 4096>), dim3(grid), dim3(TS_BLOCK), 0, c->stream, a);
+    hipLaunchKernelGGL((tile_sort_count_kernel<TS_COUNT_ITEMS, 4096>), dim3(grid), dim3(TS_BLOCK), 0, c->stream, a);
     prof_end(c);
     ZK_HIP(c, hipGetLastError());
     ZK_HIP(c, hipMemcpyAsync(c->h_scalars + 40, flag, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
