@@ -443,6 +443,13 @@ def test_kmerize_canonical_only_and_mirror_expand(ctx, K):
         ctx.kmerize(d, K, native.KMERIZE_CANONICAL_ONLY | native.KMERIZE_BOTH)
     with pytest.raises(native.ZotkError):
         ctx.kmerize(d, K, native.KMERIZE_CANONICAL_ONLY | native.KMERIZE_SUBSAMPLE, p=0.5)
+    if K & 1:
+        # odd K: a canonical list and its mirror image share no key, and the union of the two is made without a tile waiting for
+        # another (setops.hip, `disjoint`); a list that is NOT canonical (both strands in it) must be refused, not merged wrongly
+        with pytest.raises(native.ZotkError):
+            ctx.mirror_expand(ctx.upload(wk), ctx.upload(wc.astype(np.uint32)), K)
+        k, c = ctx.mirror_expand(ck, cc, K)          # (and the context is fine afterwards)
+        assert np.array_equal(k.to_host(), wk) and np.array_equal(c.to_host(), wc)
 
 
 @pytest.mark.parametrize("case", ["u150", "u150_k13", "u100", "u40", "u255", "alt_149_151", "last_short", "n_at_separator", "one_read"])

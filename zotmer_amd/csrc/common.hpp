@@ -26,6 +26,7 @@ typedef unsigned char u8;
 #define ZK_DERR_RANGE 8u          // codec64: a value (or k-mer delta) >= 2^60 has no code
 #define ZK_DERR_BAD_TAG 16u       // codec64: a word carries a tag the format does not define
 #define ZK_DERR_MISMATCH 32u      // stream_pass.hip: the pass did not write what the histogram had counted for it
+#define ZK_DERR_SHARED_KEY 64u    // setops.hip: two lists merged as disjoint share a key
 
 namespace zk {
 
@@ -131,6 +132,40 @@ __device__ __forceinline__ u64 lookback_exclusive(u64* status, u32 tile, u64 tot
             continue;
         }
         u64 take = ((need >> l) & 1ull) ? (w & ZK_ST_VALUE_MASK) : 0ull;
+        excl += wave_sum_u64(take);
+        if (incl) break;
+        idx -= 64;
+    }
+    if (l == 0) st_agent(&status[tile], st_pack(ZK_ST_INCLUSIVE, epoch, excl + total));
+    return excl;
+}
+
+// The decoupled look-back in two steps, so that work can be put between them: a tile publishes its count as soon as it has
+// it (one thread), and finds the sum over the tiles before it later (one wave; publishes the inclusive prefix)
+__device__ __forceinline__ void lookback_publish(u64* status, u32 tile, u64 total, u32 epoch) {
+    st_agent(&status[tile], st_pack(tile == 0 ? ZK_ST_INCLUSIVE : ZK_ST_PARTIAL, epoch, total));
+}
+__device__ __forceinline__ u64 lookback_resolve(u64* status, u32 tile, u64 total, u32 epoch, u32* err) {
+    const int l = lane_id();
+    if (tile == 0) return 0;
+    u64 excl = 0;
+    long long idx = (long long)tile - 1 - l;   // lane 0 looks at the nearest predecessor
+    int spins = 0;
+    while (true) {
+        const u64 w = (idx >= 0) ? ld_agent(&status[idx]) : st_pack(ZK_ST_INCLUSIVE, epoch, 0);
+        const u64 s = st_state(w, epoch);
+        const u64 incl = __ballot(s == ZK_ST_INCLUSIVE);
+        const u64 empty = __ballot(s == 0);
+        const u64 need = incl ? ((incl & (0ull - incl)) - 1) | (incl & (0ull - incl)) : ~0ull;  // lanes <= first inclusive
+        if (empty & need) {
+            if (++spins > ZK_SPIN_LIMIT) {
+                if (l == 0) atomicOr(err, ZK_DERR_SPIN_TIMEOUT | (0x40u << 8));
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        const u64 take = ((need >> l) & 1ull) ? (w & ZK_ST_VALUE_MASK) : 0ull;
         excl += wave_sum_u64(take);
         if (incl) break;
         idx -= 64;

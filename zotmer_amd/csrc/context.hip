@@ -146,6 +146,7 @@ int check_device_error(zk_ctx* c) {
     if (e & ZK_DERR_BAD_TAG) return fail(c, ZK_ERANGE, "corrupt codec64 stream (unknown tag)");
     if (e & ZK_DERR_CAPACITY) return fail(c, ZK_ENOSPC, "output does not fit the capacity given");
     if (e & ZK_DERR_COUNT_OVERFLOW) return fail(c, ZK_EOVERFLOW, "a k-mer count does not fit the count type");
+    if (e & ZK_DERR_SHARED_KEY) return fail(c, ZK_EINTERNAL, "two lists merged as disjoint share a key (the strands of a list that is not canonical?)");
     if (e & ZK_DERR_MISMATCH) return fail(c, ZK_EINTERNAL, "the first sort pass and the histogram before it disagree on the keys of a stream range");
     return fail(c, ZK_EINTERNAL, "device error word 0x%x", e);
 }

@@ -236,12 +236,15 @@ int checksum_any(zk_ctx* c, const u64* keys, const void* cnts, int count_bits, u
 int kway_union_sum(zk_ctx* c, int k, const u64* const* keys, const void* const* cnts, const uint64_t* ns, u64* out_k, void* out_c, int count_bits,
                    uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);
 // setops.hip
+// disjoint: the caller knows that no key occurs in both lists (a canonical list and its mirror image at odd K): no tile waits for
+// another; a shared key is reported (ZK_EINTERNAL), never merged wrongly in silence
 int union_sum(zk_ctx* c, const u64* A, const void* cA, u64 nA, const u64* B, const void* cB, u64 nB, u64* ok, void* oc,
-              int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4]);
+              int count_bits, uint64_t cap, uint64_t* n_out, uint64_t acgt_w[4], bool disjoint = false);
 // 32-bit counts; the B side is ONE array of (key << pack) | count words
 int union_sum_packed_b(zk_ctx* c, const u64* A, const u32* cA, u64 nA, const u64* Bp, u64 nB, int pack, u64* ok, u32* oc, uint64_t cap,
-                       uint64_t* n_out);
-int union_sum_packed_ab(zk_ctx* c, const u64* Ap, u64 nA, const u64* Bp, u64 nB, int pack, u64* ok, u32* oc, uint64_t cap, uint64_t* n_out);
+                       uint64_t* n_out, bool disjoint = false);
+int union_sum_packed_ab(zk_ctx* c, const u64* Ap, u64 nA, const u64* Bp, u64 nB, int pack, u64* ok, u32* oc, uint64_t cap, uint64_t* n_out,
+                        bool disjoint = false);
 int column_sum(zk_ctx* c, const u64* rows, uint64_t n_rows, int cols, u64* out);   // out[c] = sum of rows[r][c]
 int project(zk_ctx* c, const u64* ref, u64 n_ref, const u64* B, const u64* cB, u64 nB, u64* ok, u64* oc, uint64_t cap, uint64_t* n_out);
 int intersect_count(zk_ctx* c, const u64* A, u64 nA, const u64* B, u64 nB, uint64_t abc[3]);

@@ -226,14 +226,15 @@ static int mirror_union(zk_ctx* c, const u64* sorted, const u32* cnt, uint64_t u
         if (pack) {
             if (mh.passes) ZK_TRY(sort_keys_upper_counted(c, rk, rk2, uc, 2 * K + pack, gbits + pack, mh.raw, &sk));
             else ZK_TRY(sort_keys_upper(c, rk, rk2, uc, 2 * K + pack, gbits + pack, &sk));
-            return union_sum_packed_b(c, sorted, cnt, uc, sk, uc, pack, out_k, out_c, cap, n_out);
+            return union_sum_packed_b(c, sorted, cnt, uc, sk, uc, pack, out_k, out_c, cap, n_out, (K & 1) != 0);
         }
         ZK_TRY(sort_pairs_upper(c, rk, rk2, rv, rv2, uc, 2 * K, MIRROR_GROUP_BITS, &sk, &sv));
     } else {
         // small inputs / short k-mers: the histogram and the first pass of the sort read (c, n) and reverse-complement on load
         ZK_TRY(sort_pairs_mirrored(c, sorted, cnt, rk, rk2, rv, rv2, uc, K, &sk, &sv));
     }
-    return union_sum(c, sorted, cnt, uc, sk, sv, uc, out_k, out_c, 32, cap, n_out, nullptr);
+    // (odd K: no k-mer is its own reverse complement, and a canonical k-mer's mirror image is not canonical: the two lists share no key)
+    return union_sum(c, sorted, cnt, uc, sk, sv, uc, out_k, out_c, 32, cap, n_out, nullptr, (K & 1) != 0);
 }
 
 // zk_mirror_expand: the strands of an already counted canonical list (multi-GPU: after the exchange)
@@ -573,8 +574,8 @@ static int kmerize_full(zk_ctx* c, const u8* stream, uint64_t n_bytes, int K, bo
         u64* sk = nullptr;
         if (mhist) ZK_TRY(sort_keys_upper_counted(c, mwords, malt, uc, 2 * K + pk, mgroup + pk, mhist, &sk));
         else ZK_TRY(sort_keys_upper(c, mwords, malt, uc, 2 * K + pk, mgroup + pk, &sk));
-        if (canon_packed) return union_sum_packed_ab(c, sorted, uc, sk, uc, pk, out_k, out_c, cap, n_out);
-        return union_sum_packed_b(c, sorted, cnt, uc, sk, uc, pk, out_k, out_c, cap, n_out);
+        if (canon_packed) return union_sum_packed_ab(c, sorted, uc, sk, uc, pk, out_k, out_c, cap, n_out, (K & 1) != 0);
+        return union_sum_packed_b(c, sorted, cnt, uc, sk, uc, pk, out_k, out_c, cap, n_out, (K & 1) != 0);
     }
     const uint64_t a8 = (8 * uc + 255) & ~255ull, a4 = (4 * uc + 255) & ~255ull;
     u64 *rk, *rk2; u32 *rv, *rv2;
