@@ -67,6 +67,9 @@ __global__ void kway_bounds_kernel(KwayLists L, const u64* __restrict__ sorted_s
 
 struct KwayState {
     u64* status; u32* ticket; u32 ticket_base; u32 epoch; u32* err; u64* d_total; u32 tiles;
+#ifdef ZK_PHASES
+    int dbg_nolook;
+#endif
 };
 
 // ONE buffer: a round's outputs wait in registers until every thread has read its inputs (two barriers a round instead of one) --
@@ -229,7 +232,11 @@ __global__ __launch_bounds__(KW_BLOCK) void kway_merge_kernel(KwayLists L, const
 #pragma unroll
     for (int w2 = 0; w2 < KW_NW; w2++) { if (w2 < wave) wex += sm.wtot[w2]; tot += sm.wtot[w2]; }
     if (wave == 0) {
+#ifdef ZK_PHASES          // measurement (ZK_KWAY_NOLOOK=1; the result has gaps): what the wait for the tiles before costs
+        const u64 ex = st.dbg_nolook ? (u64)tile * 1400ull : lookback_exclusive(st.status, tile, tot, st.epoch, st.err);
+#else
         const u64 ex = lookback_exclusive(st.status, tile, tot, st.epoch, st.err);
+#endif
         if (lane == 0) {
             sm.tile_excl = ex;
             if (tile == st.tiles - 1) *st.d_total = ex + tot;
@@ -299,6 +306,9 @@ int kway_union_sum(zk_ctx* c, int k, const u64* const* keys, const void* const* 
     KwayState st = {};
     ZK_TRY(lookback_begin(c, tiles, tiles, &st.epoch, &st.ticket_base));
     st.status = c->status; st.ticket = c->d_ticket; st.err = c->d_err; st.d_total = c->d_scalars + 9; st.tiles = tiles;
+#ifdef ZK_PHASES
+    st.dbg_nolook = getenv("ZK_KWAY_NOLOOK") ? atoi(getenv("ZK_KWAY_NOLOOK")) : 0;
+#endif
     const uint64_t cb = (uint64_t)count_bits / 8;
     prof_begin(c, ZK_PROF_UNION, (8 + cb) * total);
 #define ZK_KW(CT, KT) hipLaunchKernelGGL((kway_merge_kernel<CT, KT>), dim3(tiles), dim3(KW_BLOCK), 0, c->stream, L, (const u64*)bounds, out_k, (CT*)out_c, (u64)cap, rows, st)
