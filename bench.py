@@ -343,7 +343,8 @@ def extra_config5_share(ctx, scale, synth, seed, batches=4):
 
 def extra_uniform_reads(ctx, sc, synth, seed, cfg, K, L):
     """SURVEY 8(d)'s secondary workload, "worst case U ~ I": iid bases, no k-mer occurs twice -- the look before the sort declines the
-    top-bits-first plan.  Two figures: 20 M reads as ONE batch of zk_kmerize, and 40 M reads the way `zot kmerize` counts an input
+    top-bits-first plan, and the keys of BOTH strands are sorted instead: three passes over the top 27 bits, the rest tile by tile in LDS
+    (csrc/tilesort.hip), counted there.  Two figures: 20 M reads as ONE batch of zk_kmerize, and 40 M reads the way `zot kmerize` counts an input
     that does not fit one batch -- library/engine.py KmerTable: batches counted as canonical lists, union-summed pairwise, the strands
     rebuilt once.  (50 M such reads do not fit ONE card in any order of work: their table alone is 12.6 G entries = 151 GB, and the
     strands are rebuilt from a 75 GB canonical list through two 50 GB word buffers: 277 GB + the sort arena; 40 M reads: 221 GB.)"""
@@ -352,7 +353,7 @@ def extra_uniform_reads(ctx, sc, synth, seed, cfg, K, L):
     uni = ctx.synth_reads(seed + 1, 0, Ru, L, genome=0, sub_thr=0, n_thr=synth.frac32(cfg["n"]))
     out = extra_kmerize_variant(
         ctx, "uniform", uni, K, 2, "SURVEY 8(d) uniform workload: zot kmerize k=%d on %d x %d bp reads of iid bases (no k-mer occurs twice), "
-        "one batch" % (K, Ru, L), 2 * Ru * (L - K + 1) + 1024)
+        "one batch: the keys of both strands sorted at once (passes over the top bits + a tile sort that counts)" % (K, Ru, L), 2 * Ru * (L - K + 1) + 1024)
     del uni
     ctx.release_workspace()
     R50, batches = int(40_000_000 * sc), 4
