@@ -223,14 +223,15 @@ __global__ __launch_bounds__(MRG_BLOCK) void union_sum_kernel(const u64* __restr
     }
 }
 
-// out[c] = sum over rows of in[row][c]; one workgroup, `cols` <= 8
+// out[c] += sum over rows of in[row][c]; `cols` <= 8; the workgroups take slices of the rows (out is zeroed by the caller: one workgroup
+// alone walked the 195 K rows of config 4's share in 0.38 ms)
 __global__ void column_sum_kernel(const u64* __restrict__ in, u64 rows, int cols, u64* __restrict__ out) {
     __shared__ u64 scratch[16];
     for (int c = 0; c < cols; c++) {
         u64 s = 0;
-        for (u64 r = threadIdx.x; r < rows; r += blockDim.x) s += in[r * cols + c];
+        for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (u64)gridDim.x * blockDim.x) s += in[r * cols + c];
         s = block_sum_u64(s, scratch);
-        if (threadIdx.x == 0) out[c] = s;
+        if (threadIdx.x == 0 && s) atomicAdd((unsigned long long*)&out[c], (unsigned long long)s);
     }
 }
 
@@ -302,7 +303,9 @@ __global__ __launch_bounds__(MRG_BLOCK) void intersect_kernel(const u64* __restr
 }
 
 int column_sum(zk_ctx* c, const u64* rows, uint64_t n_rows, int cols, u64* out) {
-    hipLaunchKernelGGL(column_sum_kernel, dim3(1), dim3(1024), 0, c->stream, rows, (u64)n_rows, cols, out);
+    ZK_HIP(c, hipMemsetAsync(out, 0, sizeof(u64) * cols, c->stream));
+    const u32 grid = (u32)(n_rows / 4096 + 1 < 256 ? n_rows / 4096 + 1 : 256);
+    hipLaunchKernelGGL(column_sum_kernel, dim3(grid), dim3(1024), 0, c->stream, rows, (u64)n_rows, cols, out);
     ZK_HIP(c, hipGetLastError());
     return ZK_OK;
 }
