@@ -29,6 +29,7 @@ host memory (H2D inside the timed region), and the two inputs the headline does 
 (config 3 sharded over the GPUs) through the product functions of zotmer_amd/parallel.py.  Every block is verified.
 """
 import argparse
+import ctypes as C
 import hashlib
 import json
 import os
@@ -247,6 +248,37 @@ def extra_config3(ctx, steps, scale):
                          "achieved_wall": byts / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (byts / 1e9) / (ik["ms_per_step"] / 1e3) / HBM_PEAK_GBS if ik.get("ms_per_step") else None},
             "kernels": kern_all}
+
+
+def extra_trim(ctx, steps, scale):
+    """`zot trim` (commands/trim.py:54-62) at the size of a config-4 set: 50 M (k-mer, 64-bit count) pairs with geometric counts (mean 8),
+    entries with a count in [4, inf) kept.  Verified: the number kept is the input histogram's tail, every count kept is >= 4, the
+    k-mers still ascend strictly, and the output's count histogram is the input's from 4 on."""
+    from zotmer_amd import synth
+    a = synth.config4_set_args(0, scale)
+    k, c = ctx.synth_set(a["seed"], a["first"], a["count"], a["key_bits"], mul=a["mul"], add=a["add"], mod=a["mod"])
+    lo = 4
+    ok_, oc_ = ctx.empty(k.n, np.uint64), ctx.empty(k.n, np.uint64)
+    n = C.c_uint64(0)
+
+    def run():
+        ctx._check(ctx.lib.zk_trim(ctx.h, k.ptr, c.ptr, 64, k.n, lo, 0, ok_.ptr, oc_.ptr, k.n, C.byref(n)))
+        return n.value
+
+    dt, kept, kern = timed(ctx, run, steps)
+    hin = ctx.hist(c)
+    tk, tc = ok_.view(kept), oc_.view(kept)
+    hout = ctx.hist(tc) if kept else {}
+    ok = kept == sum(v for x, v in hin.items() if x >= lo) and hout == {x: v for x, v in hin.items() if x >= lo} and ctx.first_descent(tk) == kept
+    byts = 16 * k.n + 16 * kept
+    sk = kern.get("select", {})
+    return {"workload": "zot trim of a set of %d (k-mer, 64-bit count) pairs (geometric counts, mean 8): counts >= %d kept" % (k.n, lo),
+            "value": k.n / dt / 1e9, "unit": "G (k-mer,count) pairs/s", "ms_per_step": dt * 1e3, "pairs_in": k.n, "pairs_out": kept,
+            "verified": bool(ok), "verified_by": "the input histogram's tail == the number kept == the output's histogram; strict ascent",
+            "roofline": {"bound": "hbm", "kernel": "select_kernel<TrimOp> (flag, decoupled look-back, compact)", "algorithmic_bytes": byts,
+                         "achieved": (byts / 1e9) / (sk["ms_per_step"] / 1e3) if sk.get("ms_per_step") else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (byts / 1e9) / (sk["ms_per_step"] / 1e3) / HBM_PEAK_GBS if sk.get("ms_per_step") else None},
+            "kernels": kern}
 
 
 def extra_config4_share(ctx, steps, scale):
@@ -628,6 +660,7 @@ def main():
         ctx.tune(**{k: int(v) for k, v in (kv.split("=") for kv in os.environ["ZOT_TUNE"].split(","))})
     if a.only_extra:
         fn = {"config3_dist": lambda: extra_config3(ctx, 5, a.extras_scale),
+              "trim": lambda: extra_trim(ctx, 5, a.extras_scale),
               "config4_merge_share": lambda: extra_config4_share(ctx, 3, a.extras_scale),
               "config5_share_k31": lambda: extra_config5_share(ctx, a.extras_scale, synth, seed),
               "uniform_reads": lambda: extra_uniform_reads(ctx, a.extras_scale, synth, seed, cfg, K, L),
@@ -725,6 +758,7 @@ def main():
         if par is None:
             del k, c
             for name, fn in (("config3_dist", lambda: extra_config3(ctx, 5, sc)),
+                             ("trim", lambda: extra_trim(ctx, 5, sc)),
                              ("config4_merge_share", lambda: extra_config4_share(ctx, 3, sc)),
                              ("config2_e2e_h2d", lambda: extra_e2e_h2d(ctx, stream, K, 2, out_k, out_c))):
                 try:
