@@ -75,7 +75,7 @@ int zk_upload_async(zk_ctx* ctx, void* d_dst, const void* src, uint64_t bytes);
                                     1 (default) = as early as possible (block hash tables, else tile-local ranking), 3 = tile-local ranking only,
                                     2 = a run-length pass of its own once the copies are neighbours, 0 = off */
 #define ZK_TUNE_PACKED_PAIRS 8   /* zk_kmerize / zk_mirror_expand: 1 (default) = (k-mer, count) pairs travel as one 64-bit word when the counts fit the bits above 2K */
-#define ZK_TUNE_WIDE_TILES 9     /* radix sort: 1 (default) = array passes over up to 3 * 2^30 keys use 16 K-key tiles, one workgroup per CU */
+#define ZK_TUNE_WIDE_TILES 9     /* radix sort: 1 (default) = array passes use 16 K-key tiles, one 1024-thread workgroup per CU; 0 = 8 K-key tiles, two of 512 */
 #define ZK_TUNE_STREAM_PASS 10   /* the first sort pass of zk_kmerize / zk_sort_stream: 1 (default) = static stream ranges, whole 64-byte units written
                                   * out of LDS (stream_pass.hip); 3 = the same, a tile's units leaving in two bursts (measurements; 2 is accepted and
                                   * equals 1); 0 = the look-back pipeline.  Other values are refused */

@@ -1826,7 +1826,7 @@ __global__ __launch_bounds__(512) void tag_cuts_kernel(const u64* __restrict__ k
 // host side
 // ---------------------------------------------------------------------------------------
 int launch_wide_pass(zk_ctx* c, const SortArgs& a);
-constexpr u64 WIDE_TILES_MAX_KEYS = 3ull << 30;
+constexpr u64 WIDE_TILES_MAX_KEYS = ~0ull;          // (round 4: no limit any more, see V6)
 
 template <class C>
 struct Sorter {
@@ -2169,9 +2169,11 @@ typedef Cfg<512, 16, 9, 1, 4, 32, true> V3;
 typedef Cfg<512, 16, 9, 1, 4, 32> V4;
 typedef Cfg<512, 16, 8, 1, 4, 32, true> V5;      // the pipeline with 8-bit digits: 256-byte runs, 7 passes
 // 6: the pipeline with 16 K-key tiles, one 1024-thread workgroup per CU (150 KB LDS): a digit gets 32 keys = 256 bytes per tile
-//    instead of 128 -- 3.78 vs 3.42 TB/s per pass at 2 x 10^9 keys, 3.62 vs 4.15 ms at 0.9 x 10^9, but 30.1 vs 28.0 ms at
-//    6.2 x 10^9 (one workgroup per CU: nothing else runs while it stores).  The default (3) uses it for array passes of up to
-//    3 x 2^30 keys (zk_tune ZK_TUNE_WIDE_TILES, on); pass 0 from the stream keeps the 8 K-key tiles.
+//    instead of 128 -- 3.78 vs 3.42 TB/s per pass at 2 x 10^9 keys, 3.62 vs 4.15 ms at 0.9 x 10^9.  Round 2 measured 30.1 vs 28.0 ms
+//    at 6.2 x 10^9 keys and kept the 8 K tiles above 3 x 2^30 keys; round 4 measured again: whole keys, 5 x 10^9: 23.5 vs 26.3 ms
+//    a pass; the tag pass of config 2 (6.2 x 10^9 keys, places from LDS adds, VAR 3): 18.05 vs 23.6-24.5 ms -- with the adds a tile's
+//    ranking no longer grows with its waves' ballots, and twice the keys share a tile's barriers.  The default (3) now uses it for
+//    every array pass (zk_tune ZK_TUNE_WIDE_TILES, on); pass 0 from the stream keeps the 8 K-key tiles.
 typedef Cfg<1024, 16, 9, 1, 4, 32, true> V6;
 int launch_wide_pass(zk_ctx* c, const SortArgs& a) { return Sorter<V6>::launch_pipe<SRC_ARRAY>(c, a); }
 #define ZK_SORT_DISPATCH(c, CALL) ZK_SORT_DISPATCH_V((c)->sort_variant, CALL)
