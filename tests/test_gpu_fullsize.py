@@ -70,14 +70,15 @@ def test_config2_full_size(ctx):
     finally:
         ctx.tune(stream_pass=1)
     # ... from the second pass over static segments (tag_pass.hip; pass 0 then writes two arrays), and from the block dedupe with
-    # one workgroup per CU (round 3's kernel; the default, dedupe2_kernel, made the first result)
-    for knob in (dict(tag_pass=1), dict(dedupe_variant=-1), dict(tag_words=3 - ctx_tag_words(ctx))):
+    # one workgroup per CU (round 3's kernel; the default, dedupe2_kernel, made the first result), from the tag pass that ranks every
+    # tile by ballots, and from that pass on 8 K-key tiles (the default: 16 K)
+    for knob in (dict(tag_pass=1), dict(dedupe_variant=-1), dict(tag_words=3 - ctx_tag_words(ctx)), dict(wide_tiles=0)):
         try:
             ctx.tune(**knob)
             k0, c0, _ = ctx.kmerize(d, K, out=out)
             assert k0.n == n_first and ctx.checksum(k0, c0) == want and ctx.first_descent(k0) == k0.n, knob
         finally:
-            ctx.tune(tag_pass=0, dedupe_variant=0, tag_words=ctx_tag_words(ctx))
+            ctx.tune(tag_pass=0, dedupe_variant=0, tag_words=ctx_tag_words(ctx), wide_tiles=1)
     del k0, c0, k, c, out, d
     ctx.release_workspace()
 

@@ -118,6 +118,12 @@ def test_sort_keys_every_geometry(ctx, variant):
             dk, dv = ctx.sort_pairs(ctx.upload(k), ctx.upload(v), 50)
             order = np.argsort(k, kind="stable")
             assert np.array_equal(dk.to_host(), k[order]) and np.array_equal(dv.to_host(), v[order])
+            if variant == 3:          # the default geometry hands its array passes to the 16 K-key tiles (6): its own 8 K-key tiles as well
+                try:
+                    ctx.tune(wide_tiles=0)
+                    assert np.array_equal(ctx.sort_keys(ctx.upload(x), 50).to_host(), np.sort(x))
+                finally:
+                    ctx.tune(wide_tiles=1)
     finally:
         ctx.tune(sort_variant=DEFAULT_SORT_VARIANT, pairs_variant=DEFAULT_SORT_VARIANT)
 
@@ -404,15 +410,17 @@ def test_kmerize_forced_block_dedupe(ctx, K):
             # tag_pass: the tags written by tag_pass.hip's pass over static segments (pass 0 leaves two arrays), or by the look-back pipeline
             # tag_words 2: ... which takes the places inside a digit's run from LDS adds wherever a tile holds keys of one bucket only
             # (big_block: nine such tiles)
-            for tag_words, variant, limit, tag_pass in ((1, 0, 65536, 1), (1, 0, 65536, 0), (0, 0, 65536, 1), (1, 2, 65536, 1), (1, -1, 65536, 0),
-                                                       (1, -1, 65536, 1), (1, 0, 6, 1), (0, 2, 6, 0), (2, 0, 65536, 0), (2, -1, 65536, 0)):
-                ctx.tune(dedupe_bits=18, tag_words=tag_words, dedupe_variant=variant, dedupe_limit=limit, tag_pass=tag_pass)
+            # (wide: the pass on 16 K-key tiles, the default, or on 8 K-key tiles)
+            for tag_words, variant, limit, tag_pass, wide in ((1, 0, 65536, 1, 1), (1, 0, 65536, 0, 1), (0, 0, 65536, 1, 1), (1, 2, 65536, 1, 1), (1, -1, 65536, 0, 1),
+                                                             (1, -1, 65536, 1, 1), (1, 0, 6, 1, 1), (0, 2, 6, 0, 1), (2, 0, 65536, 0, 1), (2, -1, 65536, 0, 1),
+                                                             (2, 0, 65536, 0, 0), (1, 0, 65536, 0, 0), (0, 0, 65536, 0, 0)):
+                ctx.tune(dedupe_bits=18, tag_words=tag_words, dedupe_variant=variant, dedupe_limit=limit, tag_pass=tag_pass, wide_tiles=wide)
                 k, c, st = ctx.kmerize(d, K)
-                assert np.array_equal(k.to_host(), want["kmers"]), (name, tag_words, variant, limit, tag_pass)
-                assert np.array_equal(c.to_host(), want["counts"]), (name, tag_words, variant, limit, tag_pass)
+                assert np.array_equal(k.to_host(), want["kmers"]), (name, tag_words, variant, limit, tag_pass, wide)
+                assert np.array_equal(c.to_host(), want["counts"]), (name, tag_words, variant, limit, tag_pass, wide)
                 assert list(st.acgt) == want["acgt"] and st.n_unique == len(want["kmers"])
     finally:
-        ctx.tune(dedupe_bits=0, tag_words=native.DEFAULT_TAG_WORDS, dedupe_variant=0, dedupe_limit=65536, tag_pass=0)
+        ctx.tune(dedupe_bits=0, tag_words=native.DEFAULT_TAG_WORDS, dedupe_variant=0, dedupe_limit=65536, tag_pass=0, wide_tiles=1)
 
 
 @pytest.mark.parametrize("K", [4, 12, 24, 25, 31, 32])
