@@ -1388,10 +1388,12 @@ struct PipeSmem {
 // before the block dedupe is the last one, nobody looks at the order inside a block -- all that must survive is that a block's keys
 // stay together, i.e. the order of the BUCKETS of the pass before.  A tile that lies inside one such bucket (all but one in 1500 at
 // config 2's size) has nothing to keep; a tile in which a bucket begins (SortArgs::straddle) is ranked by the ballots as before.
+// 4 = the same for whole keys: the FIRST array pass after a pass over the stream, whatever the plan -- the stream pass has no order of
+// its own, so all the second pass must keep is the first one's buckets.
 template <class C, int SRC, int VAR = 0>
 __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a, u32 tiles) {
     constexpr int BLOCK = C::BLOCK, ITEMS = C::ITEMS, RADIX = C::RADIX, NW = C::NW, DPT = C::DPT, TILE = C::TILE;
-    constexpr bool ATOM = VAR == 3, TAGS = VAR == 2 || VAR == 3;
+    constexpr bool ATOM = VAR == 3 || VAR == 4, TAGS = VAR == 2 || VAR == 3;
     static_assert(!ATOM || (SRC == SRC_ARRAY && NW >= 2), "the counters of the adds are the first two rows of the per-wave counters");
     static_assert(C::ROUNDS == 1, "the pipeline parks a whole tile in LDS");
     constexpr int NS = RADIX / 64;          // scanner workgroups: 64 digits each
@@ -1885,6 +1887,8 @@ struct Sorter {
                    SRC == SRC_STREAM ? a.n_bytes + 8 * a.n : (a.tags_out ? 12 : 16) * a.n);
         if (SRC == SRC_ARRAY && a.tags_out && a.straddle)
             hipLaunchKernelGGL((pass_pipe_kernel<C, SRC_ARRAY, 3>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
+        else if (SRC == SRC_ARRAY && a.straddle)
+            hipLaunchKernelGGL((pass_pipe_kernel<C, SRC_ARRAY, 4>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
         else if (SRC == SRC_ARRAY && a.tags_out)
             hipLaunchKernelGGL((pass_pipe_kernel<C, SRC_ARRAY, 2>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
         else if (SRC == SRC_ARRAY && a.prof_tag == ZK_PROF_PASS_PACKED)
@@ -2118,7 +2122,8 @@ struct Sorter {
             a.ghist = ghist + p * C::RADIX;
             a.tags_out = (tags && p == plan.passes - 1) ? 1 : 0;
             a.straddle = nullptr;
-            if (a.tags_out && c->tag_words >= 2) {
+            // (p == 1: the pass before came from the stream and had no order to keep)
+            if ((a.tags_out || p == 1) && c->tag_words >= 2 && C::PIPE) {
                 // the tiles in which a bucket of the pass before begins keep their order (see pass_pipe_kernel, VAR 3): one bit each
                 const u32 tile = keys_pass_tile(c, n), tiles = (u32)div_up(n, tile);
                 u32* bm;
