@@ -1,24 +1,13 @@
+# The array passes on 8 K-key tiles (two 512-thread workgroups per CU) against 16 K-key tiles (one of 1024 threads), config 2:
+# ZK_TUNE_WIDE_TILES 0 / 1 (the default), with the tag pass ranking by LDS adds (tag_words 2) and by ballots (1)
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-for v in 1; do
-ZK_WIDE_ALL=$v ZOTK_LIB=build/libzotk_phases.so timeout -k 10 300 python - > gpurun_out/wide_all_$v.json 2> gpurun_out/wide_all_$v.err <<PY || { tail -5 gpurun_out/wide_all_$v.err; exit 1; }
-import json, numpy as np
-from zotmer_amd import native, synth
-cfg = synth.CONFIGS["config2"]
-ctx = native.Context(0)
-R = cfg["reads"]
-d = ctx.synth_reads(synth.DEFAULT_SEED, 0, R, cfg["L"], genome=cfg["genome"], sub_thr=synth.frac32(cfg["sub"]), n_thr=synth.frac32(cfg["n"]))
-cap = int(2 * (cfg["genome"] + R * cfg["L"] * cfg["sub"] * 22) * 1.25) + (1 << 20)
-outs = (ctx.empty(cap, np.uint64), ctx.empty(cap, np.uint32))
-res = []
-for rep in range(3):
-    ctx.profile(True)
-    ctx.kmerize(d, 25, out=outs)
-    ctx.sync()
-    p = ctx.profile_read(); ctx.profile(False)
-    res.append({k: round(v["ms"], 2) for k, v in p.items() if v["launches"]})
-print(json.dumps({"local": $v, "runs": res}))
+for t in "wide_tiles=0,tag_words=2" "wide_tiles=1,tag_words=2" "wide_tiles=0,tag_words=1" "wide_tiles=1,tag_words=1"; do
+  ZOT_TUNE=$t timeout -k 10 300 python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/wide_$t.json 2> gpurun_out/wide_$t.err || { tail -5 gpurun_out/wide_$t.err; continue; }
+  python - <<PY
+import json
+d=json.load(open("gpurun_out/wide_$t.json"))
+print("$t", round(d["ms_per_step"],2), d["verified_checksums"], {k:round(v["ms_per_step"],2) for k,v in d["pipeline"]["kernels"].items() if k in ("pass_keys","pass_packed")})
 PY
-cat gpurun_out/wide_all_$v.json
 done
