@@ -25,7 +25,7 @@ struct zk_ctx {
                                // else collapse_kernel one pass before the copies are neighbours), 3 = collapse_kernel only,
                                // 2 = a run-length pass of its own once the copies are neighbours (the round's first form), 0 = off
     int side_div = 8;          // ... side list capacity = n / side_div (tests shrink it to force the fallback)
-    int pairs_variant = 2;     // ... for (key, u32) pairs
+    int pairs_variant = 7;     // ... for (key, u32) pairs: 7 = the pipeline with a payload (1024 threads x 8 pairs), 2 = one workgroup per tile, one serial chain per digit
     int stream_pass = 1;       // the first sort pass (from the base stream): 1 = static ranges, whole 64-byte units written from LDS
                                // (stream_pass.hip; 3 = a tile's units leave in two bursts, for measurements), 0 = the look-back pipeline
     int tag_words = 2;         // zk_kmerize, block dedupe after two passes with at most 32 key bits below the blocks: the second pass writes

@@ -231,7 +231,9 @@ __global__ void first_newline_kernel(const u8* __restrict__ stream, u64 n_bytes,
 template <class C, int SRC> struct NextTile;
 template <class C> struct NextTile<C, SRC_ARRAY> {
     u64 key[C::ITEMS];
+    u32 val[C::ITEMS];          // (pairs only: never touched, hence never allocated, otherwise)
     u32 live = 0;
+    template <bool PAIRS = false>
     __device__ __forceinline__ void issue(const SortArgs& a, u32 t, int tid, int wave, int lane) {
         const u64 base = (u64)t * C::TILE + (u64)wave * (64 * C::ITEMS) + lane;
         if ((u64)(t + 1) * C::TILE <= a.n) {
@@ -239,6 +241,11 @@ template <class C> struct NextTile<C, SRC_ARRAY> {
             const u64* p = a.kin + base;
 #pragma unroll
             for (int i = 0; i < C::ITEMS; i++) key[i] = p[i * 64];
+            if constexpr (PAIRS) {
+                const u32* q = a.vin + base;
+#pragma unroll
+                for (int i = 0; i < C::ITEMS; i++) val[i] = q[i * 64];
+            }
             live = (C::ITEMS >= 32) ? ~0u : ((1u << C::ITEMS) - 1u);
             return;
         }
@@ -248,6 +255,7 @@ template <class C> struct NextTile<C, SRC_ARRAY> {
             const u64 idx = base + (u64)i * 64;
             const bool ok = idx < a.n;
             key[i] = ok ? a.kin[idx] : 0ull;
+            if constexpr (PAIRS) val[i] = ok ? a.vin[idx] : 0u;
             live |= (ok ? 1u : 0u) << i;
         }
     }
@@ -1363,13 +1371,14 @@ __device__ __forceinline__ u32 steal_tile(const SortArgs& a, u32 x, u32 tiles) {
     return 0xffffffffu;
 }
 
-template <class C>
+template <class C, bool PAIRS = false>
 struct PipeSmem {
     static constexpr bool IMG_FITS = sizeof(TileImage<C::TILE>) <= sizeof(u16) * C::NW * C::RADIX;
     // the image takes the whole counter area: room for record-aligned tiles, whose byte span exceeds TILE
     static constexpr int IMG_WORDS = (int)(sizeof(u16) * C::NW * C::RADIX / 8);     // per array (codes, valid)
     static constexpr int IMG_T = IMG_FITS ? (IMG_WORDS - 3) * 16 : 16;
     u64 exch[C::TILE];              // tile A, grouped by digit, until its offsets are known
+    u32 exv[PAIRS ? C::TILE : 1];   // ... and its payloads
     union {
         u16 cnt[C::NW][C::RADIX];
         TileImage<PipeSmem::IMG_T> img;     // stream source: the 2-bit image of tile B, dead before cnt is zeroed
@@ -1393,11 +1402,13 @@ struct PipeSmem {
 template <class C, int SRC, int VAR = 0>
 __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a, u32 tiles) {
     constexpr int BLOCK = C::BLOCK, ITEMS = C::ITEMS, RADIX = C::RADIX, NW = C::NW, DPT = C::DPT, TILE = C::TILE;
-    constexpr bool ATOM = VAR == 3 || VAR == 4, TAGS = VAR == 2 || VAR == 3;
+    constexpr bool PAIRS = VAR == 5 || VAR == 6;          // a 32-bit payload travels with every key (SortArgs::vin / vout)
+    constexpr bool ATOM = VAR == 3 || VAR == 4 || VAR == 6, TAGS = VAR == 2 || VAR == 3;
+    static_assert(!PAIRS || SRC == SRC_ARRAY, "pairs come from arrays");
     static_assert(!ATOM || (SRC == SRC_ARRAY && NW >= 2), "the counters of the adds are the first two rows of the per-wave counters");
     static_assert(C::ROUNDS == 1, "the pipeline parks a whole tile in LDS");
     constexpr int NS = RADIX / 64;          // scanner workgroups: 64 digits each
-    __shared__ PipeSmem<C> sm;
+    __shared__ PipeSmem<C, VAR == 5 || VAR == 6> sm;
     static_assert(SRC == SRC_ARRAY || PipeSmem<C>::IMG_FITS, "the tile image lives in the counter area");
     static_assert(SRC == SRC_ARRAY || (ITEMS == 16 && PipeSmem<C>::IMG_WORDS <= 2 * BLOCK), "stream source: 16 consecutive windows per thread");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1501,7 +1512,10 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
     __syncthreads();          // sm.ticket is rewritten below
     NextTile<C, SRC> nx;
     u32 pending = 0;
-    auto issue_loads = [&](u32 t) { nx.issue(a, t, tid, wave, lane); };
+    auto issue_loads = [&](u32 t) {
+        if constexpr (SRC == SRC_ARRAY) nx.template issue<PAIRS>(a, t, tid, wave, lane);
+        else nx.issue(a, t, tid, wave, lane);
+    };
     if (vB) {
         if (tid == 0) pending = atomicAdd(a.xticket + 32 * myx, 1u);     // for the tile AFTER the one being loaded
         issue_loads(tB);
@@ -1515,6 +1529,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
         u32 tid_o = (u32)tid;
         asm volatile("" : "+v"(tid_o));
         u64 key[ITEMS];
+        u32 val[PAIRS ? ITEMS : 1];
         u32 rank2[ITEMS / 2];          // two 16-bit ranks per register
         u32 live = 0;
         u32 tC = 0;
@@ -1531,6 +1546,14 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
             if constexpr (SRC == SRC_ARRAY) {
 #pragma unroll
                 for (int i = 0; i < ITEMS; i++) key[i] = nx.key[i];
+                if constexpr (PAIRS) {
+#pragma unroll
+                    for (int i = 0; i < ITEMS; i++) val[i] = nx.val[i];
+                    if (a.mirror_K > 0) {          // (the strand rebuild's first pass: the keys are mirrored as they are loaded)
+#pragma unroll
+                        for (int i = 0; i < ITEMS; i++) key[i] = revcomp(a.mirror_K, key[i]);
+                    }
+                }
                 live = nx.live;
             } else {
                 __syncthreads();      // the waves that parked the previous tile are done with the counters (same LDS)
@@ -1642,6 +1665,11 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                     const u64* p = a.kin + (u64)tC * TILE + (u64)(wave * (64 * ITEMS) + (int)(tid_o & 63u));
 #pragma unroll
                     for (int i = 0; i < ITEMS; i++) nx.key[i] = p[i * 64];
+                    if constexpr (PAIRS) {
+                        const u32* q = a.vin + (u64)tC * TILE + (u64)(wave * (64 * ITEMS) + (int)(tid_o & 63u));
+#pragma unroll
+                        for (int i = 0; i < ITEMS; i++) nx.val[i] = q[i * 64];
+                    }
                     nx.live = (1u << ITEMS) - 1u;
                 }
             }          // (stream source: its next tile is only 16-32 bytes per thread; asking for it here as well was slower, 31.5 vs 30.8 ms)
@@ -1742,6 +1770,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                     if (slot0 + (i0 + g) * BLOCK < totalA) {
                         if constexpr (TAGS) reinterpret_cast<u32*>(a.kout)[pos[g]] = (u32)kk[g];
                         else a.kout[pos[g]] = kk[g];
+                        if constexpr (PAIRS) a.vout[pos[g]] = sm.exv[slot0 + (i0 + g) * BLOCK];
                     }
             }
         }
@@ -1755,7 +1784,11 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
         for (int i = 0; i < ITEMS; i++) {
             const u32 d = (u32)(key[i] >> a.shift) & dmask;
             const u32 inwave = (ATOM && atomB) ? 0u : (u32)sm.cnt[wave][d];
-            if ((live >> i) & 1u) sm.exch[sm.digit_off[d] + inwave + ((rank2[i / 2] >> (16 * (i & 1))) & 0xffffu)] = key[i];
+            const u32 at = sm.digit_off[d] + inwave + ((rank2[i / 2] >> (16 * (i & 1))) & 0xffffu);
+            if ((live >> i) & 1u) {
+                sm.exch[at] = key[i];
+                if constexpr (PAIRS) sm.exv[at] = val[i];
+            }
         }
         tileA = tB;
         totalA = sm.total_live;
@@ -1780,6 +1813,7 @@ __global__ __launch_bounds__(C::BLOCK, C::WPE) void pass_pipe_kernel(SortArgs a,
                     const u64 idx = base + (u64)i * 64;
                     const bool ok = idx < a.n;
                     nx.key[i] = ok ? a.kin[idx] : 0ull;
+                    if constexpr (PAIRS) nx.val[i] = ok ? a.vin[idx] : 0u;
                     nx.live |= (ok ? 1u : 0u) << i;
                 }
             } else {
@@ -1900,6 +1934,33 @@ struct Sorter {
       }
       return ZK_OK;
     }
+    // the same pipeline with a 32-bit payload (VAR 5; 6 = places from LDS adds where a.straddle allows)
+    static constexpr bool PIPE_PAIRS = C::PIPE && C::ITEMS <= 8;          // (a tile of pairs is 12 bytes an entry: 8 K of them)
+    static int launch_pipe_pairs(zk_ctx* c, SortArgs a) {
+      if constexpr (PIPE_PAIRS) {
+        const u32 tiles = (u32)div_up(a.n, C::TILE);
+        if (tiles == 0) return ZK_OK;
+        u32 grid = (u32)c->num_cus * (sizeof(PipeSmem<C, true>) > 80 * 1024 ? 1 : 2);
+        if (grid > tiles) grid = tiles;
+        grid += C::RADIX / 64;          // the scanner workgroups
+        ZK_TRY(lookback_begin(c, (uint64_t)tiles * C::RADIX, grid, &a.epoch, &a.ticket_base));
+        ZK_TRY(part16_begin(c, (uint64_t)tiles * C::RADIX, &a.part));
+        ZK_HIP(c, hipMemsetAsync(c->d_xticket, 0, 8 * 32 * sizeof(u32), c->stream));
+        a.xticket = c->d_xticket;
+        a.nx = 1u;
+        a.glog = 0;
+        a.status = c->status;
+        a.ticket = c->d_ticket;
+        a.err = c->d_err;
+        a.dbg = nullptr; a.dbg2 = nullptr;
+        prof_begin(c, ZK_PROF_PASS_PAIRS, 24 * a.n);
+        if (a.straddle) hipLaunchKernelGGL((pass_pipe_kernel<C, SRC_ARRAY, 6>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
+        else hipLaunchKernelGGL((pass_pipe_kernel<C, SRC_ARRAY, 5>), dim3(grid), dim3(C::BLOCK), 0, c->stream, a, tiles);
+        prof_end(c);
+        ZK_HIP(c, hipGetLastError());
+      }
+      return ZK_OK;
+    }
     // keys per tile of the geometry launch_keys_pass uses for this many keys
     static u32 keys_pass_tile(zk_ctx* c, uint64_t n) {
         if constexpr (C::PIPE && C::RBITS == 9 && C::BLOCK == 512) { if (c->wide_tiles && n <= WIDE_TILES_MAX_KEYS) return 16384u; }
@@ -1979,8 +2040,11 @@ struct Sorter {
     // mirror_K > 0: sort (rc(src_k[i]), src_v[i]) instead, without writing the mirrored keys first: the histogram and
     // the first pass apply rc on load; src_k / src_v are only read, keys/alt/vals/valt are the two work buffers.
     // lo_bit > 0: only the bits [lo_bit, key_bits) are sorted (the input is already ordered by the bits below)
+    // unordered: nobody needs pairs of equal keys to stay in their order (the mirrored keys of the strand rebuild are all different) and
+    // the order the keys arrive in means nothing: the first pass takes its places from LDS adds in every tile, the second wherever a
+    // tile lies inside one bucket of the first (pipeline geometries only)
     static int sort_pairs(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, u64** rk, u32** rv,
-                          const u64* src_k = nullptr, const u32* src_v = nullptr, int mirror_K = 0, int lo_bit = 0) {
+                          const u64* src_k = nullptr, const u32* src_v = nullptr, int mirror_K = 0, int lo_bit = 0, bool unordered = false) {
         PassPlan plan = make_plan(key_bits - lo_bit, C::RBITS, lo_bit);
         u64* ghist;
         ZK_TRY(arena_alloc(c, sizeof(u64) * MAX_PASSES * C::RADIX, (void**)&ghist));
@@ -1993,6 +2057,22 @@ struct Sorter {
             a.kin = in; a.kout = out; a.vin = vi; a.vout = vo; a.shift = plan.shift[p]; a.bits = plan.bits[p];
             a.ghist = ghist + p * C::RADIX;
             a.mirror_K = (p == 0) ? mirror_K : 0;
+            if constexpr (PIPE_PAIRS) {
+                a.straddle = nullptr;
+                if (unordered && p <= 1) {
+                    const u32 tiles = (u32)div_up(n, C::TILE);
+                    u32* bm;
+                    ZK_TRY(arena_alloc(c, sizeof(u32) * (tiles / 32 + 1), (void**)&bm));
+                    ZK_HIP(c, hipMemsetAsync(bm, 0, sizeof(u32) * (tiles / 32 + 1), c->stream));
+                    if (p == 1) {
+                        hipLaunchKernelGGL(straddle_kernel, dim3((C::RADIX + 255) / 256), dim3(256), 0, c->stream, (const u64*)(ghist + (p - 1) * C::RADIX),
+                                           1u << plan.bits[p - 1], (u32)C::TILE, bm);
+                        ZK_HIP(c, hipGetLastError());
+                    }
+                    a.straddle = bm;
+                }
+                ZK_TRY(launch_pipe_pairs(c, a));
+            } else
             ZK_TRY((launch_pass<SRC_ARRAY, true>(c, a)));
             in = out; vi = vo;
             out = (out == keys) ? alt : keys;
@@ -2180,6 +2260,8 @@ typedef Cfg<512, 16, 8, 1, 4, 32, true> V5;      // the pipeline with 8-bit digi
 //    ranking no longer grows with its waves' ballots, and twice the keys share a tile's barriers.  The default (3) now uses it for
 //    every array pass (zk_tune ZK_TUNE_WIDE_TILES, on); pass 0 from the stream keeps the 8 K-key tiles.
 typedef Cfg<1024, 16, 9, 1, 4, 32, true> V6;
+// 7 (pairs only): the pipeline with a payload -- 1024 threads x 8 pairs, 8 K-pair tiles, 115 KB of LDS, one workgroup per CU
+typedef Cfg<1024, 8, 9, 1, 4, 32, true> V7;
 int launch_wide_pass(zk_ctx* c, const SortArgs& a) { return Sorter<V6>::launch_pipe<SRC_ARRAY>(c, a); }
 #define ZK_SORT_DISPATCH(c, CALL) ZK_SORT_DISPATCH_V((c)->sort_variant, CALL)
 #define ZK_SORT_DISPATCH_V(v, CALL)                 \
@@ -2197,6 +2279,7 @@ static int sort_keys_lsd(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_bit
     ZK_SORT_DISPATCH(c, sort_keys(c, keys, alt, n, key_bits, result));
 }
 static int sort_pairs_lsd(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, u64** rk, u32** rv) {
+    if (c->pairs_variant == 7) return Sorter<V7>::sort_pairs(c, keys, alt, vals, valt, n, key_bits, rk, rv);
     ZK_SORT_DISPATCH_V(c->pairs_variant, sort_pairs(c, keys, alt, vals, valt, n, key_bits, rk, rv));
 }
 
@@ -2252,6 +2335,7 @@ int sort_keys_upper_counted(zk_ctx* c, u64* keys, u64* alt, uint64_t n, int key_
 int sort_pairs_upper(zk_ctx* c, u64* keys, u64* alt, u32* vals, u32* valt, uint64_t n, int key_bits, int lo_bit, u64** rk, u32** rv) {
     *rk = keys; *rv = vals;
     if (n == 0) return ZK_OK;
+    if (c->pairs_variant == 7) return Sorter<V7>::sort_pairs(c, keys, alt, vals, valt, n, key_bits, rk, rv, nullptr, nullptr, 0, lo_bit);
     ZK_SORT_DISPATCH_V(c->pairs_variant, sort_pairs(c, keys, alt, vals, valt, n, key_bits, rk, rv, nullptr, nullptr, 0, lo_bit));
 }
 
@@ -2261,6 +2345,8 @@ int sort_pairs_mirrored(zk_ctx* c, const u64* src_k, const u32* src_v, u64* keys
                         u64** rk, u32** rv, int lo_bit) {
     *rk = keys; *rv = vals;
     if (n == 0) return ZK_OK;
+    // (mirrored keys are all different, and their order of arrival means nothing: `unordered`)
+    if (c->pairs_variant == 7) return Sorter<V7>::sort_pairs(c, keys, alt, vals, valt, n, 2 * K, rk, rv, src_k, src_v, K, lo_bit, true);
     ZK_SORT_DISPATCH_V(c->pairs_variant, sort_pairs(c, keys, alt, vals, valt, n, 2 * K, rk, rv, src_k, src_v, K, lo_bit));
 }
 int sort_pairs_rbits(zk_ctx* c) { return (c->pairs_variant == 0 || c->pairs_variant == 1 || c->pairs_variant == 5) ? 8 : 9; }
