@@ -79,8 +79,10 @@ def measured_traffic(kernel_substr, n_keys_now):
                 continue
             if d.get("_kernel_source_sha256") != kernel_source_hash():
                 continue
+            subs = (kernel_substr,) if isinstance(kernel_substr, str) else tuple(kernel_substr)
             for name, v in d.items():
-                if isinstance(v, dict) and kernel_substr in name and abs(v.get("n_keys", 0) - n_keys_now) <= 0.001 * max(n_keys_now, 1):
+                if isinstance(v, dict) and any(x in name for x in subs) and v.get("launches", 0) >= 1 and v.get("traffic_bytes_per_launch", 0) > 1e9 \
+                        and abs(v.get("n_keys", 0) - n_keys_now) <= 0.001 * max(n_keys_now, 1):
                     best = dict(bytes=v["traffic_bytes_per_launch"], profile="profiles/%s/pmc_traffic.json" % sub)
     return best
 
@@ -811,10 +813,12 @@ def main():
         # array pass runs once per step and the pass that reads the base stream is its equal); the other is listed beside it
         cands = {"pass_keys": ("pass_pipe_kernel<array> (the LSD radix pass over the key array, persistent two-stage pipeline: 8 B/key read, and "
                                "written 4 B/key -- the 32-bit tags the block dedupe needs -- or 8 B/key)",
-                               "pass_pipe_kernel<zk::Cfg<512, 16, 9, 1, 4, 32, true>, 0, "),
+                               # (the tag pass of the default plan: 16 K-key tiles, places from LDS adds; or its other forms by zk_tune)
+                               ("pass_pipe_kernel<zk::Cfg<1024, 16, 9, 1, 4, 32, true>, 0, 3>", "pass_pipe_kernel<zk::Cfg<1024, 16, 9, 1, 4, 32, true>, 0, 2>",
+                                "pass_pipe_kernel<zk::Cfg<512, 16, 9, 1, 4, 32, true>, 0, 3>", "pass_pipe_kernel<zk::Cfg<512, 16, 9, 1, 4, 32, true>, 0, 2>")),
                  "pass_stream": ("stream_pass0_kernel (pass 0 over static stream ranges: 2-bit image -> canonical 64-bit keys, grouped by digit in LDS, "
                                  "whole 64-byte units out; 1 B/stream byte + 8 B/key)",
-                                 "stream_pass0_kernel<9, 8, true, true>")}
+                                 "stream_pass0_kernel<9, 8, true, true")}
         empty = dict(launches=0, ms=0.0, bytes=0)
         dom = max(cands, key=lambda n: prof.get(n, empty)["ms"])
         pk = prof.get(dom, empty)
@@ -832,6 +836,8 @@ def main():
                 g = (v["bytes"] / 1e9) / (v["ms"] / 1e3)
                 o = {"kernel": cands_all[n][0], "achieved": g, "frac": g / HBM_PEAK_GBS, "launches": v["launches"],
                      "avg_launch_ms": v["ms"] / v["launches"]}
+                tr = measured_traffic(cands_all[n][1], st.n_windows)
+                o["traffic"] = tr["bytes"] if tr else None
                 if n == "rle":          # (the tag also times the 0.1 ms run-length count of the look before the sort: per step, not per launch)
                     o["ms_per_step"] = v["ms"] / a.steps
                     del o["avg_launch_ms"]
